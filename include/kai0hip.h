@@ -1,0 +1,222 @@
+/* kai0hip.h — C ABI of libkai0hip.so: the MI355X (gfx950 / CDNA4) kernels under the pi0.5 hot path.
+ *
+ * The reference (OpenDriveLab/kai0, a fork of openpi) has NO C/FFI boundary on this path: every op below
+ * is a `torch.nn.functional` call inside src/openpi/models_pytorch/{pi0_pytorch,gemma_pytorch}.py and the
+ * patched transformers_replace layer library, lowered by torch to cuBLAS/cuDNN/Inductor.  This header is
+ * the seam the new framework inserts: each entry cites the reference op it replaces.
+ *
+ * Conventions
+ *   - plain C, `int` return: 0 = ok, <0 = error; message via kai0_last_error() (thread-local).
+ *   - the caller (PyTorch-ROCm host code) owns every device buffer and passes raw device pointers,
+ *     explicit shapes/strides (in ELEMENTS unless a name says bytes) and the hipStream_t to launch on.
+ *   - no allocation, no host synchronisation inside: every entry point is hipGraph-capturable.
+ *   - bf16 = IEEE bfloat16 (torch.bfloat16), f32 = float. Rounding to bf16 is round-to-nearest-even,
+ *     applied at exactly the points where the reference's bf16-typed torch ops round.
+ */
+#ifndef KAI0HIP_H
+#define KAI0HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* kai0_stream_t; /* hipStream_t */
+
+const char* kai0_last_error(void);
+int kai0_abi_version(void);
+/* device properties probe: writes CU count, LDS bytes/CU, gcnArchName (<=63 chars) */
+int kai0_device_info(int device, int* n_cu, int* lds_bytes, char* arch_name64);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogue.  C[M,N] (+)= epilogue(A(M,K) * B(K,N))
+ *
+ * Replaces: every nn.Linear on the path — SigLIP q/k/v/out/fc1/fc2 (modeling_siglip.py:366-383,411,
+ * 420-432), projector (modeling_paligemma.py:91-99), Gemma q/k/v/o/gate/up/down
+ * (modeling_gemma.py:113-126,269-280; gemma_pytorch.py:172-174,222), the attention matmuls
+ * QK^T and PV of eager_attention_forward (modeling_gemma.py:230-253, modeling_siglip.py:325-345),
+ * and their autograd dgrad/wgrad.
+ *
+ * Operand storage: each operand is a row-major 2-D matrix in memory.
+ *   a_kc=1: A stored [M][K] (K contiguous)          a_kc=0: A stored [K][M] (M contiguous)
+ *   b_kc=1: B stored [N][K] (K contiguous; nn.Linear weight)   b_kc=0: B stored [K][N]
+ * so (a_kc,b_kc) = (1,1) is y = x W^T, (1,0) is dgrad dx = dy W, (0,0) is wgrad dW = dy^T x.
+ * All leading dimensions and K-/M-/N-contiguous extents must be multiples of 8 elements (16 B) and the
+ * base pointers 16-B aligned; M, N, K themselves are arbitrary multiples of 8 along contiguous dims.
+ *
+ * Row remap (lets a flattened [B*rows] operand address a padded [B][S_pad] buffer without a copy):
+ *   stored_row(r) = rpb ? (r / rpb) * bs + (r % rpb) + off : r
+ * applied to the stored-row index of A / B (the M or N index when *_kc=1, the K index when *_kc=0)
+ * and to the output row (C, pre_out and residual share c_*).
+ *
+ * Batching: grid z in [0,batch): z1 = z / batch_inner, z2 = z % batch_inner; operand X is offset by
+ * z1*sX1 + z2*sX2 elements.
+ *
+ * Epilogue, in this order, on the f32 accumulator v (every step that the reference performs as a bf16
+ * torch op rounds to bf16 exactly there):
+ *   v += bias[col]                       (bias bf16 or f32)
+ *   v = bf16(v)                          (the Linear / matmul output)
+ *   if scale != 1: v = bf16(v * scale)   (attention logits: modeling_gemma.py:243)
+ *   if act == 1:   pre_out = v (optional); v = bf16(gelu_tanh(v))   (modeling_siglip.py:428-430)
+ *   if gate:       v = bf16(v * gate[row / gate_rpb][col])          (_gated_residual, modeling_gemma.py:209-227)
+ *   if residual:   v = bf16(v + residual[row][col])
+ *   if accumulate: v = v + C_old  (f32 out: exact; bf16 out: rounded once)
+ *   C = v (bf16, or f32 when out_f32)
+ */
+typedef struct kai0_gemm_desc {
+    const void* A;
+    const void* B;
+    void* C;
+    int32_t M, N, K;
+    int32_t a_kc, b_kc;
+    int64_t lda, ldb, ldc;
+    int32_t batch, batch_inner;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+    int32_t a_rpb, b_rpb, c_rpb, _pad0;
+    int64_t a_bs, a_off, b_bs, b_off, c_bs, c_off;
+    const void* bias;
+    int32_t bias_f32;
+    float scale;
+    int32_t act;
+    int32_t out_f32;
+    void* pre_out;
+    const void* gate;
+    int32_t gate_rpb;
+    int32_t accumulate;
+    int64_t gate_ld;
+    const void* residual;
+    int64_t ldr;
+    int64_t sR1, sR2;
+} kai0_gemm_desc;
+
+int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
+
+/* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C)
+ * Replaces the f32 islands: patch-embed conv as im2col GEMM (modeling_siglip.py:220-226), adaRMS
+ * `dense` (modeling_gemma.py:83-104), time MLP and action in/out projections
+ * (pi0_pytorch.py:100-105,264-297,364-371) and their backward. */
+int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                  float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate,
+                  kai0_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation.
+ * RMSNorm (modeling_gemma.py:66-81): y = bf16( f32(x) * rsqrt(mean(x^2) + eps) * (1 + w) ), w f32.
+ * adaRMS  (modeling_gemma.py:83-104): mod = [scale|shift|gate] f32 [B][3*D];
+ *         y = bf16( xhat * (1 + scale) + shift ); gate_out = bf16(gate)  [B][D]
+ * rows = number of token rows, rows_per_batch maps a row to its batch entry of `mod`.
+ * rstd (f32 [rows]) is saved for backward.  */
+int kai0_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int D, float eps,
+                     kai0_stream_t stream);
+int kai0_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, void* dx,
+                     float* dw_partial, int dw_blocks, int64_t rows, int D, kai0_stream_t stream);
+int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gate_out, float* rstd, int64_t rows,
+                    int rows_per_batch, int D, float eps, kai0_stream_t stream);
+int kai0_adarms_bwd(const void* dy, const void* dgate, const void* x, const float* mod, const float* rstd,
+                    void* dx, float* dmod, int64_t rows, int rows_per_batch, int D, kai0_stream_t stream);
+/* LayerNorm over the last dim (modeling_siglip.py:439-441,756): bf16 x, bf16 w/b, f32 statistics. */
+int kai0_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                       int64_t rows, int D, float eps, kai0_stream_t stream);
+int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                       void* dx, float* dwb_partial, int dwb_blocks, int64_t rows, int D,
+                       kai0_stream_t stream);
+/* column sums of per-block partials [blocks][ncols] f32 -> out (bf16 or f32) */
+int kai0_reduce_partials(const float* partial, int blocks, int ncols, void* out, int out_f32,
+                         kai0_stream_t stream);
+/* bias gradient: out[n] = sum_m dy[m][n]  (dy bf16 [M][ld], out bf16 or f32) */
+int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
+                     void* out, int out_f32, kai0_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RoPE, half-split layout (modeling_gemma.py:149-194): x is [B][S_ld][H][HD] bf16, in place;
+ * rows row0..row0+S of every batch entry are rotated; pos int32 [B][S]; inv_freq f32 [HD/2] is the host's
+ * 10000^(-2i/HD) table (ROPE_INIT_FUNCTIONS["default"]); cos/sin are computed in f32, rounded to bf16, then
+ * out = bf16( bf16(x*cos) + bf16(rot(x)*sin) ).  inverse=1 applies the transpose (backward). */
+int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_freq, int B, int S, int64_t s_ld_rows,
+                      int64_t row0, int H, int HD, int inverse, kai0_stream_t stream);
+
+/* Masked row softmax for the prefix-LM mask (pi0_pytorch.py:52-81,156-159; modeling_gemma.py:243-248).
+ * scores bf16 [B][Sq*H][ld] already scaled; row r of batch b is query s = q0 + r / H.
+ * allowed(b,s,j) = kcode[b][j] <= qcode[b][s] && j < Sk, where kcode = pad ? cumsum(att) : INT_MAX and
+ * qcode = pad ? cumsum(att) : -1 (the host builds both: integer logic, bit-exact with make_att_2d_masks).
+ * qcode == NULL means "no mask" (SigLIP).  probs = bf16(softmax_f32(scores)); masked columns and the
+ * padding columns [Sk, ld) are written as 0.  */
+int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode, const int32_t* kcode,
+                          int B, int Sq, int H, int Sk, int64_t ld, int64_t batch_stride, int q0,
+                          int64_t qcode_ld, int64_t kcode_ld, kai0_stream_t stream);
+/* dscores = bf16( (probs * (dprobs - sum_j dprobs*probs)) * scale ) */
+int kai0_softmax_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int Sk, int64_t ld,
+                     float scale, kai0_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise pieces.
+ * GeGLU (modeling_gemma.py:122-126): h = bf16( bf16(gelu_tanh(g)) * u ) */
+int kai0_geglu_fwd(const void* g, const void* u, void* h, int64_t n, kai0_stream_t stream);
+int kai0_geglu_bwd(const void* dh, const void* g, const void* u, void* dg, void* du, int64_t n,
+                   kai0_stream_t stream);
+/* dx = bf16(dy * gelu_tanh'(pre)) (SigLIP fc1 activation backward) */
+int kai0_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, kai0_stream_t stream);
+/* y = silu(x), f32 (time MLP, pi0_pytorch.py:289-297) */
+int kai0_silu_fwd_f32(const float* x, float* y, int64_t n, kai0_stream_t stream);
+int kai0_silu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, kai0_stream_t stream);
+/* gated residual backward (modeling_gemma.py:209-227): for out = x + y*gate[b]:
+ *   dy = bf16(dout * gate[b]);  dgate[b][c] = bf16( sum_rows_in_b dout*y )  (f32 accumulation) */
+int kai0_gated_bwd(const void* dout, const void* y, const void* gate, void* dy, void* dgate, int64_t rows,
+                   int rows_per_batch, int D, kai0_stream_t stream);
+/* token embedding gather * sqrt(D) (gemma_pytorch.py:88-89; pi0_pytorch.py:213-216):
+ * out[b][row0 + t] = bf16( table[tok[b][t]] * scale ); out rows have stride out_ld, batch stride out_bs */
+int kai0_embed_gather(const void* table, const int64_t* tokens, void* out, int B, int T, int D, float scale,
+                      int64_t out_bs, int64_t out_row0, int64_t out_ld, kai0_stream_t stream);
+/* backward, deterministic: dtable[tok] = bf16( sum over occurrences of bf16(dout*scale) ) for every token id
+ * that occurs; rows of ids that do not occur are left untouched (caller zero-fills the dense gradient). */
+int kai0_embed_grad(const void* dout, const int64_t* tokens, void* dtable, int B, int T, int D, float scale,
+                    int64_t dout_bs, int64_t dout_row0, int64_t dout_ld, kai0_stream_t stream);
+/* casts and adds */
+int kai0_cast_f32_to_bf16(const float* x, void* y, int64_t n, kai0_stream_t stream);
+int kai0_cast_bf16_to_f32(const void* x, float* y, int64_t n, kai0_stream_t stream);
+int kai0_add_bf16(const void* a, const void* b, void* out, int64_t n, kai0_stream_t stream);
+int kai0_add_f32(const float* a, const float* b, float* out, int64_t n, kai0_stream_t stream);
+/* strided 2-D copy of bf16 rows: dst[b][dst_row0 + r][0:D] = src[b][src_row0 + r][0:D] */
+int kai0_copy_rows_bf16(const void* src, void* dst, int B, int rows, int D, int64_t src_bs, int64_t src_row0,
+                        int64_t src_ld, int64_t dst_bs, int64_t dst_row0, int64_t dst_ld,
+                        kai0_stream_t stream);
+/* im2col for the 14x14/stride-14 patch conv (modeling_siglip.py:220-226):
+ * img f32 [N][3][224][224] -> cols f32 [N*256][588], k = c*196 + ky*14 + kx (Conv2d weight order) */
+int kai0_patch_im2col(const float* img, float* cols, int n_img, int C, int HW, int P, kai0_stream_t stream);
+/* out = bf16(x + pos[row % n_pos]) : patch embeddings + position embedding, cast to bf16
+ * (modeling_siglip.py:271-281, 777-778) */
+int kai0_add_pos_cast(const float* x, const float* pos, void* out, int64_t rows, int n_pos, int D,
+                      kai0_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flow matching glue (pi0_pytorch.py:326-328,373,401-419).
+ * x_t = t*noise + (1-t)*a ; u_t = noise - a                         (f32, [B][HA]) */
+int kai0_flow_mix(const float* noise, const float* actions, const float* time, float* x_t, float* u_t, int B,
+                  int HA, kai0_stream_t stream);
+/* loss = (u - v)^2 ; dv = -2 (u - v) * gscale                         (f32) */
+int kai0_mse_fwd(const float* u, const float* v, float* loss, int64_t n, kai0_stream_t stream);
+int kai0_mse_bwd(const float* u, const float* v, const float* dloss, float* dv, int64_t n,
+                 kai0_stream_t stream);
+/* Euler step x += dt * v (f32) */
+int kai0_euler_step(float* x, const float* v, float dt, int64_t n, kai0_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer (train_pytorch.py:469-475,557-561; optimizer.py:15-85).
+ * sumsq: out[0] += sum(g^2) over a bf16 or f32 buffer (f32 atomics; caller zeroes out). */
+int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, kai0_stream_t stream);
+/* Fused AdamW on a flat shard: master/m/v f32, grad bf16 or f32, writes the bf16 (or f32) model copy.
+ * clip_coef is read from device memory (coef[0]) so the step stays graph/stream ordered:
+ *   g = grad * coef[0]; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p = p - lr * (m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps) + wd * p)    (torch.optim.AdamW semantics) */
+int kai0_adamw(float* master, float* m, float* v, const void* grad, int grad_f32, void* model_param,
+               int param_f32, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+               float bias_c1, float bias_c2, const float* clip_coef, kai0_stream_t stream);
+/* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) ; norm_out[0] = sqrt(sumsq[0])
+ * (torch.nn.utils.clip_grad_norm_) */
+int kai0_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, kai0_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAI0HIP_H */

@@ -1,0 +1,573 @@
+// elementwise.hip — the HBM-bound glue of the pi0.5 path: RoPE, masked softmax, GeGLU, gated residual,
+// embedding gather, casts, patch im2col, flow-matching mix / MSE / Euler.  Every kernel moves 16 B per lane
+// per access where the layout allows and does its arithmetic in f32, rounding to bf16 exactly where the
+// reference's bf16-typed torch ops do.
+#include "common.h"
+#include "../../include/kai0hip.h"
+#include <limits.h>
+
+namespace {
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+inline int ew_grid(int64_t n_items, int per_block) {
+    int64_t b = (n_items + per_block - 1) / per_block;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------- RoPE
+// x: [B][S_ld rows][H][HD]; thread owns 4 consecutive frequency indices i4..i4+3 of one (b,s) row and walks
+// the heads, so the sin/cos of a position is computed once and shared by all heads.
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const int32_t* __restrict__ pos,
+                                                   const float* __restrict__ inv_freq, int B, int S, int64_t s_ld,
+                                                   int64_t row0, int H, int HD, int inverse) {
+    const int tpr = HD >> 3;              // threads per row (HD/2 freqs, 4 per thread)
+    const int rpb = 256 / tpr;            // rows per block
+    const int rl = threadIdx.x / tpr;
+    const int i4 = (threadIdx.x - rl * tpr) * 4;
+    if (rl >= rpb) return;
+    const int64_t nrows = (int64_t)B * S;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rl; r < nrows; r += (int64_t)gridDim.x * rpb) {
+        const int b = (int)(r / S), s = (int)(r - (int64_t)b * S);
+        const float p = (float)pos[r];
+        float c[4], sn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ang = inv_freq[i4 + e] * p;
+            c[e] = rbf(cosf(ang));
+            sn[e] = rbf(sinf(ang));
+            if (inverse) sn[e] = -sn[e];
+        }
+        bf16_t* xr = x + ((int64_t)b * s_ld + row0 + s) * (int64_t)H * HD;
+        for (int h = 0; h < H; ++h) {
+            bf16_t* p1 = xr + h * HD + i4;
+            bf16_t* p2 = p1 + (HD >> 1);
+            bf16x4 a = *reinterpret_cast<const bf16x4*>(p1);
+            bf16x4 bq = *reinterpret_cast<const bf16x4*>(p2);
+            bf16x4 o1, o2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x1 = bf2f(a[e]), x2 = bf2f(bq[e]);
+                // q*cos + rotate_half(q)*sin with every product and the sum rounded to bf16
+                o1[e] = f2bf(rbf(x1 * c[e]) + rbf(-x2 * sn[e]));
+                o2[e] = f2bf(rbf(x2 * c[e]) + rbf(x1 * sn[e]));
+            }
+            *reinterpret_cast<bf16x4*>(p1) = o1;
+            *reinterpret_cast<bf16x4*>(p2) = o2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- masked softmax
+constexpr int SM_MAXC = 8;  // ld <= 4096
+__global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* __restrict__ scores, bf16_t* __restrict__ probs,
+                                                               const int32_t* __restrict__ qcode,
+                                                               const int32_t* __restrict__ kcode, int B, int Sq, int H,
+                                                               int Sk, int64_t ld, int64_t bstride, int q0,
+                                                               int64_t qld, int64_t kld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows_pb = (int64_t)Sq * H;
+    const int64_t rows = rows_pb * B;
+    const int nchunk = (int)(ld >> 3);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / rows_pb);
+        const int64_t rr = row - (int64_t)b * rows_pb;
+        const int s = q0 + (int)(rr / H);
+        const int qc = qcode ? qcode[(int64_t)b * qld + s] : INT_MAX;
+        const bf16_t* sp = scores + (int64_t)b * bstride + rr * ld;
+        bf16_t* pp = probs + (int64_t)b * bstride + rr * ld;
+        float v[SM_MAXC][8];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                ld8(sp + ci * 8, v[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = ci * 8 + e;
+                    bool ok = j < Sk;
+                    if (ok && qcode) ok = kcode[(int64_t)b * kld + j] <= qc;
+                    v[c][e] = ok ? v[c][e] : -INFINITY;
+                    m = fmaxf(m, v[c][e]);
+                }
+            }
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        if (m > -INFINITY) {
+#pragma unroll
+            for (int c = 0; c < SM_MAXC; ++c) {
+                const int ci = c * 64 + lane;
+                if (ci < nchunk) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[c][e] = expf(v[c][e] - m);  // exp(-inf) = 0 for masked columns
+                        sum += v[c][e];
+                    }
+                }
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (m > -INFINITY) ? v[c][e] * inv : 0.f;
+                st8(pp + ci * 8, o);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ probs, const bf16_t* __restrict__ dprobs,
+                                                          bf16_t* __restrict__ dscores, int64_t rows, int Sk, int64_t ld,
+                                                          float scale) {
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (int)(ld >> 3);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        float p[SM_MAXC][8], dp[SM_MAXC][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                ld8(probs + row * ld + ci * 8, p[c]);
+                ld8(dprobs + row * ld + ci * 8, dp[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (ci * 8 + e >= Sk) { p[c][e] = 0.f; dp[c][e] = 0.f; }
+                    dot += p[c][e] * dp[c][e];
+                }
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rbf(p[c][e] * (dp[c][e] - dot)) * scale;
+                st8(dscores + row * ld + ci * 8, o);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- GeGLU
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u,
+                                                        bf16_t* __restrict__ h, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float gv[8], uv[8], o[8];
+        ld8(g + i * 8, gv);
+        ld8(u + i * 8, uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rbf(gelu_tanh_f(gv[e])) * uv[e];
+        st8(h + i * 8, o);
+    }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ g,
+                                                        const bf16_t* __restrict__ u, bf16_t* __restrict__ dg,
+                                                        bf16_t* __restrict__ du, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float dv[8], gv[8], uv[8], og[8], ou[8];
+        ld8(dh + i * 8, dv);
+        ld8(g + i * 8, gv);
+        ld8(u + i * 8, uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = rbf(gelu_tanh_f(gv[e]));
+            ou[e] = dv[e] * a;
+            og[e] = rbf(dv[e] * uv[e]) * gelu_tanh_grad_f(gv[e]);
+        }
+        st8(dg + i * 8, og);
+        st8(du + i * 8, ou);
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ pre,
+                                                       bf16_t* __restrict__ dx, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float dv[8], pv[8], o[8];
+        ld8(dy + i * 8, dv);
+        ld8(pre + i * 8, pv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = dv[e] * gelu_tanh_grad_f(pv[e]);
+        st8(dx + i * 8, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = v / (1.0f + expf(-v));
+    }
+}
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        const float sg = 1.0f / (1.0f + expf(-v));
+        dx[i] = dy[i] * (sg * (1.0f + v * (1.0f - sg)));
+    }
+}
+
+// gated residual backward: block per batch entry, thread owns 8 columns
+__global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                        const bf16_t* __restrict__ gate, bf16_t* __restrict__ dy,
+                                                        bf16_t* __restrict__ dgate, int rpb, int D) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c0 = tid * 8; c0 < D; c0 += 256 * 8) {
+        float gt[8], acc[8];
+        ld8(gate + (int64_t)b * D + c0, gt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int i = 0; i < rpb; ++i) {
+            const int64_t row = (int64_t)b * rpb + i;
+            float dv[8], yv[8], o[8];
+            ld8(dout + row * D + c0, dv);
+            ld8(y + row * D + c0, yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = dv[e] * gt[e];
+                acc[e] += dv[e] * yv[e];
+            }
+            st8(dy + row * D + c0, o);
+        }
+        st8(dgate + (int64_t)b * D + c0, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(256) void embed_gather_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ tok,
+                                                           bf16_t* __restrict__ out, int T, int D, float scale,
+                                                           int64_t out_bs, int64_t out_row0, int64_t out_ld) {
+    const int r = blockIdx.x;  // b*T + t
+    const int b = r / T, t = r - b * T;
+    const bf16_t* src = table + tok[r] * (int64_t)D;
+    bf16_t* dst = out + (int64_t)b * out_bs + (out_row0 + t) * out_ld;
+    for (int c0 = threadIdx.x * 8; c0 < D; c0 += 256 * 8) {
+        float v[8];
+        ld8(src + c0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= scale;
+        st8(dst + c0, v);
+    }
+}
+// Deterministic dense embedding gradient: block i owns flattened token i; only the FIRST occurrence of a
+// token id sums (in f32) the rows of every occurrence and writes the bf16 gradient row once.
+__global__ __launch_bounds__(256) void embed_grad_kernel(const bf16_t* __restrict__ dout, const int64_t* __restrict__ tok,
+                                                         bf16_t* __restrict__ dtable, int n, int T, int D, float scale,
+                                                         int64_t bs, int64_t row0, int64_t ld) {
+    __shared__ int earlier;
+    const int i = blockIdx.x;
+    const int64_t my = tok[i];
+    if (threadIdx.x == 0) earlier = 0;
+    __syncthreads();
+    int found = 0;
+    for (int j = threadIdx.x; j < i; j += 256) found |= (tok[j] == my);
+    if (found) earlier = 1;  // benign race: all writers store 1
+    __syncthreads();
+    if (earlier) return;
+    for (int c0 = threadIdx.x * 8; c0 < D; c0 += 256 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int j = i; j < n; ++j) {
+            if (tok[j] != my) continue;  // block-uniform
+            const int b = j / T, t = j - b * T;
+            float v[8];
+            ld8(dout + (int64_t)b * bs + (row0 + t) * ld + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += rbf(v[e] * scale);
+        }
+        st8(dtable + my * (int64_t)D + c0, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------ casts / adds / copies
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
+        f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        st8(y + i * 8, v);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += 256) y[i] = f2bf(x[i]);
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        ld8(x + i * 8, v);
+        *reinterpret_cast<f32x4*>(y + i * 8) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(y + i * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += 256) y[i] = bf2f(x[i]);
+}
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ o, int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8], y[8];
+        ld8(a + i * 8, x);
+        ld8(b + i * 8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        st8(o + i * 8, x);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += 256) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows,
+                                                        int D, int64_t sbs, int64_t sr0, int64_t sld, int64_t dbs,
+                                                        int64_t dr0, int64_t dld) {
+    const int64_t r = blockIdx.x;  // b*rows + i
+    const int b = (int)(r / rows), i = (int)(r - (int64_t)b * rows);
+    const bf16_t* s = src + (int64_t)b * sbs + (sr0 + i) * sld;
+    bf16_t* d = dst + (int64_t)b * dbs + (dr0 + i) * dld;
+    for (int c0 = threadIdx.x * 8; c0 < D; c0 += 256 * 8)
+        *reinterpret_cast<bf16x8*>(d + c0) = *reinterpret_cast<const bf16x8*>(s + c0);
+}
+
+// ------------------------------------------------------------------------------------------ patch embed
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ cols, int n_img,
+                                                     int C, int HW, int P) {
+    const int G = HW / P;               // patches per side
+    const int Kd = C * P * P;
+    const int64_t total = (int64_t)n_img * G * G * Kd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % Kd);
+        const int64_t pr = i / Kd;
+        const int px = (int)(pr % G), py = (int)((pr / G) % G);
+        const int n = (int)(pr / ((int64_t)G * G));
+        const int c = k / (P * P), kk = k - c * P * P;
+        const int ky = kk / P, kx = kk - ky * P;
+        cols[i] = img[(((int64_t)n * C + c) * HW + (py * P + ky)) * HW + (px * P + kx)];
+    }
+}
+__global__ __launch_bounds__(256) void add_pos_cast_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                           bf16_t* __restrict__ out, int64_t rows, int n_pos, int D) {
+    const int64_t total = rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / D;
+        const int c = (int)(i - r * D);
+        out[i] = f2bf(x[i] + pos[(r % n_pos) * D + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ flow matching
+__global__ __launch_bounds__(256) void flow_mix_kernel(const float* __restrict__ noise, const float* __restrict__ act,
+                                                       const float* __restrict__ time, float* __restrict__ xt,
+                                                       float* __restrict__ ut, int B, int HA) {
+    const int64_t total = (int64_t)B * HA;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float t = time[i / HA];
+        const float nz = noise[i], a = act[i];
+        xt[i] = t * nz + (1.0f - t) * a;
+        ut[i] = nz - a;
+    }
+}
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                      float* __restrict__ loss, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = u[i] - v[i];
+        loss[i] = d * d;
+    }
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                      const float* __restrict__ dl, float* __restrict__ dv, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dv[i] = -2.0f * (u[i] - v[i]) * dl[i];
+}
+__global__ __launch_bounds__(256) void euler_kernel(float* __restrict__ x, const float* __restrict__ v, float dt, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = x[i] + dt * v[i];
+}
+
+}  // namespace
+
+#define S_(st) ((hipStream_t)(st))
+
+KAI0_API int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_freq, int B, int S, int64_t s_ld_rows,
+                               int64_t row0, int H, int HD, int inverse, kai0_stream_t stream) {
+    KAI0_REQUIRE(HD % 8 == 0 && HD >= 8 && HD <= 2048, "kai0_rope_inplace: HD=%d unsupported", HD);
+    KAI0_REQUIRE(256 % (HD / 8) == 0, "kai0_rope_inplace: HD/8 must divide 256 (HD=%d)", HD);
+    if (B * S <= 0) return 0;
+    const int rpb = 256 / (HD / 8);
+    hipLaunchKernelGGL(rope_kernel, dim3(ew_grid((int64_t)B * S, rpb)), dim3(256), 0, S_(stream), (bf16_t*)x, pos,
+                       inv_freq, B, S, s_ld_rows, row0, H, HD, inverse);
+    return kai0_check_launch("kai0_rope_inplace");
+}
+
+KAI0_API int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode, const int32_t* kcode, int B,
+                                   int Sq, int H, int Sk, int64_t ld, int64_t batch_stride, int q0, int64_t qcode_ld,
+                                   int64_t kcode_ld, kai0_stream_t stream) {
+    KAI0_REQUIRE(ld % 8 == 0 && ld <= 4096 && Sk <= ld, "kai0_softmax_mask_fwd: ld=%lld (Sk=%d) unsupported",
+                 (long long)ld, Sk);
+    KAI0_REQUIRE((qcode == nullptr) == (kcode == nullptr), "kai0_softmax_mask_fwd: qcode/kcode must both be set");
+    const int64_t rows = (int64_t)B * Sq * H;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_mask_fwd_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream),
+                       (const bf16_t*)scores, (bf16_t*)probs, qcode, kcode, B, Sq, H, Sk, ld, batch_stride, q0,
+                       qcode_ld, kcode_ld);
+    return kai0_check_launch("kai0_softmax_mask_fwd");
+}
+
+KAI0_API int kai0_softmax_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int Sk, int64_t ld,
+                              float scale, kai0_stream_t stream) {
+    KAI0_REQUIRE(ld % 8 == 0 && ld <= 4096 && Sk <= ld, "kai0_softmax_bwd: ld=%lld unsupported", (long long)ld);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream), (const bf16_t*)probs,
+                       (const bf16_t*)dprobs, (bf16_t*)dscores, rows, Sk, ld, scale);
+    return kai0_check_launch("kai0_softmax_bwd");
+}
+
+KAI0_API int kai0_geglu_fwd(const void* g, const void* u, void* h, int64_t n, kai0_stream_t stream) {
+    KAI0_REQUIRE(n % 8 == 0, "kai0_geglu_fwd: n must be a multiple of 8");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, S_(stream), (const bf16_t*)g,
+                       (const bf16_t*)u, (bf16_t*)h, n / 8);
+    return kai0_check_launch("kai0_geglu_fwd");
+}
+KAI0_API int kai0_geglu_bwd(const void* dh, const void* g, const void* u, void* dg, void* du, int64_t n,
+                            kai0_stream_t stream) {
+    KAI0_REQUIRE(n % 8 == 0, "kai0_geglu_bwd: n must be a multiple of 8");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, S_(stream), (const bf16_t*)dh,
+                       (const bf16_t*)g, (const bf16_t*)u, (bf16_t*)dg, (bf16_t*)du, n / 8);
+    return kai0_check_launch("kai0_geglu_bwd");
+}
+KAI0_API int kai0_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, kai0_stream_t stream) {
+    KAI0_REQUIRE(n % 8 == 0, "kai0_gelu_bwd: n must be a multiple of 8");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, S_(stream), (const bf16_t*)dy,
+                       (const bf16_t*)pre, (bf16_t*)dx, n / 8);
+    return kai0_check_launch("kai0_gelu_bwd");
+}
+KAI0_API int kai0_silu_fwd_f32(const float* x, float* y, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), x, y, n);
+    return kai0_check_launch("kai0_silu_fwd_f32");
+}
+KAI0_API int kai0_silu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), dy, x, dx, n);
+    return kai0_check_launch("kai0_silu_bwd_f32");
+}
+KAI0_API int kai0_gated_bwd(const void* dout, const void* y, const void* gate, void* dy, void* dgate, int64_t rows,
+                            int rows_per_batch, int D, kai0_stream_t stream) {
+    KAI0_REQUIRE(D % 8 == 0, "kai0_gated_bwd: D must be a multiple of 8");
+    KAI0_REQUIRE(rows_per_batch > 0 && rows % rows_per_batch == 0, "kai0_gated_bwd: rows %% rows_per_batch != 0");
+    const int B = (int)(rows / rows_per_batch);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(gated_bwd_kernel, dim3(B), dim3(256), 0, S_(stream), (const bf16_t*)dout, (const bf16_t*)y,
+                       (const bf16_t*)gate, (bf16_t*)dy, (bf16_t*)dgate, rows_per_batch, D);
+    return kai0_check_launch("kai0_gated_bwd");
+}
+KAI0_API int kai0_embed_gather(const void* table, const int64_t* tokens, void* out, int B, int T, int D, float scale,
+                               int64_t out_bs, int64_t out_row0, int64_t out_ld, kai0_stream_t stream) {
+    KAI0_REQUIRE(D % 8 == 0 && out_ld % 8 == 0, "kai0_embed_gather: D and out_ld must be multiples of 8");
+    if (B * T <= 0) return 0;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(B * T), dim3(256), 0, S_(stream), (const bf16_t*)table, tokens,
+                       (bf16_t*)out, T, D, scale, out_bs, out_row0, out_ld);
+    return kai0_check_launch("kai0_embed_gather");
+}
+KAI0_API int kai0_embed_grad(const void* dout, const int64_t* tokens, void* dtable, int B, int T, int D, float scale,
+                             int64_t dout_bs, int64_t dout_row0, int64_t dout_ld, kai0_stream_t stream) {
+    KAI0_REQUIRE(D % 8 == 0 && dout_ld % 8 == 0, "kai0_embed_grad: D and dout_ld must be multiples of 8");
+    if (B * T <= 0) return 0;
+    hipLaunchKernelGGL(embed_grad_kernel, dim3(B * T), dim3(256), 0, S_(stream), (const bf16_t*)dout, tokens,
+                       (bf16_t*)dtable, B * T, T, D, scale, dout_bs, dout_row0, dout_ld);
+    return kai0_check_launch("kai0_embed_grad");
+}
+KAI0_API int kai0_cast_f32_to_bf16(const float* x, void* y, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    KAI0_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "kai0_cast_f32_to_bf16: unaligned");
+    hipLaunchKernelGGL(cast_f2b_kernel, dim3(ew_grid(n / 8 + 1, 256)), dim3(256), 0, S_(stream), x, (bf16_t*)y, n);
+    return kai0_check_launch("kai0_cast_f32_to_bf16");
+}
+KAI0_API int kai0_cast_bf16_to_f32(const void* x, float* y, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    KAI0_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "kai0_cast_bf16_to_f32: unaligned");
+    hipLaunchKernelGGL(cast_b2f_kernel, dim3(ew_grid(n / 8 + 1, 256)), dim3(256), 0, S_(stream), (const bf16_t*)x, y, n);
+    return kai0_check_launch("kai0_cast_bf16_to_f32");
+}
+KAI0_API int kai0_add_bf16(const void* a, const void* b, void* out, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_grid(n / 8 + 1, 256)), dim3(256), 0, S_(stream), (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)out, n);
+    return kai0_check_launch("kai0_add_bf16");
+}
+KAI0_API int kai0_add_f32(const float* a, const float* b, float* out, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), a, b, out, n);
+    return kai0_check_launch("kai0_add_f32");
+}
+KAI0_API int kai0_copy_rows_bf16(const void* src, void* dst, int B, int rows, int D, int64_t src_bs, int64_t src_row0,
+                                 int64_t src_ld, int64_t dst_bs, int64_t dst_row0, int64_t dst_ld,
+                                 kai0_stream_t stream) {
+    KAI0_REQUIRE(D % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0, "kai0_copy_rows_bf16: D/ld must be multiples of 8");
+    if ((int64_t)B * rows <= 0) return 0;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(B * rows), dim3(256), 0, S_(stream), (const bf16_t*)src, (bf16_t*)dst,
+                       rows, D, src_bs, src_row0, src_ld, dst_bs, dst_row0, dst_ld);
+    return kai0_check_launch("kai0_copy_rows_bf16");
+}
+KAI0_API int kai0_patch_im2col(const float* img, float* cols, int n_img, int C, int HW, int P, kai0_stream_t stream) {
+    KAI0_REQUIRE(HW % P == 0, "kai0_patch_im2col: image size %d not divisible by patch %d", HW, P);
+    const int64_t total = (int64_t)n_img * (HW / P) * (HW / P) * C * P * P;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_(stream), img, cols, n_img, C, HW, P);
+    return kai0_check_launch("kai0_patch_im2col");
+}
+KAI0_API int kai0_add_pos_cast(const float* x, const float* pos, void* out, int64_t rows, int n_pos, int D,
+                               kai0_stream_t stream) {
+    if (rows * D <= 0) return 0;
+    hipLaunchKernelGGL(add_pos_cast_kernel, dim3(ew_grid(rows * D, 256)), dim3(256), 0, S_(stream), x, pos,
+                       (bf16_t*)out, rows, n_pos, D);
+    return kai0_check_launch("kai0_add_pos_cast");
+}
+KAI0_API int kai0_flow_mix(const float* noise, const float* actions, const float* time, float* x_t, float* u_t, int B,
+                           int HA, kai0_stream_t stream) {
+    if ((int64_t)B * HA <= 0) return 0;
+    hipLaunchKernelGGL(flow_mix_kernel, dim3(ew_grid((int64_t)B * HA, 256)), dim3(256), 0, S_(stream), noise, actions,
+                       time, x_t, u_t, B, HA);
+    return kai0_check_launch("kai0_flow_mix");
+}
+KAI0_API int kai0_mse_fwd(const float* u, const float* v, float* loss, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), u, v, loss, n);
+    return kai0_check_launch("kai0_mse_fwd");
+}
+KAI0_API int kai0_mse_bwd(const float* u, const float* v, const float* dloss, float* dv, int64_t n,
+                          kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), u, v, dloss, dv, n);
+    return kai0_check_launch("kai0_mse_bwd");
+}
+KAI0_API int kai0_euler_step(float* x, const float* v, float dt, int64_t n, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(euler_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), x, v, dt, n);
+    return kai0_check_launch("kai0_euler_step");
+}

@@ -1,0 +1,381 @@
+// gemm_bf16.hip — the bf16 MFMA GEMM under every Linear and attention matmul of the pi0.5 path.
+//
+// gfx950 design:
+//   * 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA 16x16x32 bf16 tiles.
+//   * operands go HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction), never
+//     through VGPRs; two 32 KiB stages (A+B) double-buffered => 64 KiB/block, 2 blocks per CU.
+//   * the LDS image is lane-linear (DMA constraint), so the bank-conflict XOR swizzle is applied on the
+//     per-lane GLOBAL source address and undone on the ds_read address (same involution both sides).
+//   * K-contiguous operands are read with ds_read_b128; contraction-strided operands (dgrad's W,
+//     wgrad's dY/X, attention's V) are read with ds_read_b64_tr_b16 (hardware 4x16 transpose), so no
+//     operand is ever transposed through HBM.
+//   * epilogue: accumulators -> wave-private LDS slab (f32) -> each lane owns 8 consecutive columns of a
+//     row: bias/scale/GELU/gate/residual are applied with 16-B vector loads and the tile leaves as 16-B
+//     stores. Rounding to bf16 happens exactly where the reference's bf16 torch ops round.
+//   * 1-D grid, XCD-aware bijective remap + grouped raster so the blocks sharing an A/B panel sit on one
+//     XCD's L2.
+#include "common.h"
+#include "../../include/kai0hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;       // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int GROUP_M = 8;
+
+__device__ __attribute__((aligned(16))) uint32_t kai0_zero16[4] = {0, 0, 0, 0};
+
+struct RowMap {
+    int32_t rpb;
+    int64_t bs, off;
+    // rows are < 2^31: 32-bit divide (a 64-bit one costs ~100 VALU ops)
+    __device__ __forceinline__ int64_t operator()(int r) const {
+        if (rpb == 0) return r;
+        const int q = r / rpb;
+        return (int64_t)q * bs + (r - q * rpb) + off;
+    }
+};
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int batch_inner;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+    RowMap amap, bmap, cmap;
+    const void* bias;
+    int bias_f32;
+    float scale;
+    int act;
+    int out_f32;
+    bf16_t* pre_out;
+    const bf16_t* gate;
+    int gate_rpb;
+    int accumulate;
+    int64_t gate_ld;
+    const bf16_t* residual;
+    int64_t ldr, sR1, sR2;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))lds_dst_wave_uniform, 16, 0, 0);
+}
+
+// Swizzle key of a contraction-strided (MC) tile row r: key(r) = (r & 3) | (((r >> 3) & 1) << 2).
+// It spreads the 8 k-rows that a 32-lane half of ds_read_b64_tr_b16 touches ({0..3, 8..11} + 4h) over the 8
+// distinct 32-B segments of the 256-B bank row.  Both the DMA source address and the read address apply it.
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> tile (XCD-aware bijective remap, then grouped raster) -------------------------
+    const int nwg = gridDim.x;
+    int pid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = pid & 7, idx = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tile_m, tile_n;
+    {
+        const int width = GROUP_M * p.tiles_n;
+        const int group = pid / width;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = pid - group * width;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int z = blockIdx.y;
+    const int z1 = z / p.batch_inner, z2 = z - z1 * p.batch_inner;
+    const bf16_t* __restrict__ Ab = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const bf16_t* __restrict__ Bb = p.B + z1 * p.sB1 + z2 * p.sB2;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(kai0_zero16);
+
+    // ---- staging source addresses (per thread: 4 DMA pieces per operand per K-tile) -------------
+    // K-contiguous tile [128 rows][64 k]: piece q=wave*4+j covers rows q*8..q*8+7; lane -> row q*8+(lane>>3),
+    //   16-B slot lane&7 which holds source chunk (lane&7)^(row&7).
+    // contraction-strided tile [64 k][128 cols]: piece q covers k-rows q*4..q*4+3; lane -> k-row q*4+(lane>>4),
+    //   slot lane&15 holding source chunk (lane&15)^(key(row)<<1).
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+    bool a_ok[4], b_ok[4];
+    int a_kchunk = 0, b_kchunk = 0;  // KC: k offset (elements) of this lane's chunk inside the K-tile
+    if constexpr (A_KC) {
+        const int c = (lane & 7) ^ (lane >> 3);
+        a_kchunk = c * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave * 4 + j) * 8 + (lane >> 3);
+            const int R = m0 + r;
+            a_ok[j] = R < p.M;
+            a_src[j] = Ab + p.amap(a_ok[j] ? R : 0) * p.lda + c * 8;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 4 + j;
+            const int key = (lane >> 4) | (((q >> 1) & 1) << 2);
+            const int c = (lane & 15) ^ (key << 1);
+            const int col = m0 + c * 8;
+            a_ok[j] = col < p.M;
+            a_src[j] = Ab + col;  // + stored_row(k)*lda added per K-tile
+        }
+    }
+    if constexpr (B_KC) {
+        const int c = (lane & 7) ^ (lane >> 3);
+        b_kchunk = c * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave * 4 + j) * 8 + (lane >> 3);
+            const int R = n0 + r;
+            b_ok[j] = R < p.N;
+            b_src[j] = Bb + p.bmap(b_ok[j] ? R : 0) * p.ldb + c * 8;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 4 + j;
+            const int key = (lane >> 4) | (((q >> 1) & 1) << 2);
+            const int c = (lane & 15) ^ (key << 1);
+            const int col = n0 + c * 8;
+            b_ok[j] = col < p.N;
+            b_src[j] = Bb + col;
+        }
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE_BYTES + wave * 4096;
+        char* sb = sa + TILE_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t* src;
+            if constexpr (A_KC) {
+                src = (a_ok[j] && (k0 + a_kchunk) < p.K) ? a_src[j] + k0 : zsrc;
+            } else {
+                const int kr = k0 + (wave * 4 + j) * 4 + (lane >> 4);
+                src = (a_ok[j] && kr < p.K) ? a_src[j] + p.amap(kr) * p.lda : zsrc;
+            }
+            glds16(src, sa + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t* src;
+            if constexpr (B_KC) {
+                src = (b_ok[j] && (k0 + b_kchunk) < p.K) ? b_src[j] + k0 : zsrc;
+            } else {
+                const int kr = k0 + (wave * 4 + j) * 4 + (lane >> 4);
+                src = (b_ok[j] && kr < p.K) ? b_src[j] + p.bmap(kr) * p.ldb : zsrc;
+            }
+            glds16(src, sb + j * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside an operand tile), fixed per thread -----------------
+    const int l15 = lane & 15, g = lane >> 4;
+    // KC: row = w*64 + t*16 + l15 ; chunk = ks*4 + g ; addr = row*128 + ((chunk ^ (row&7)) << 4)
+    // MC: cols n = w*64 + t*16 ; k-row r = ks*32 + 8g + 4h + (l15>>2) ; key = (l15>>2)|((g&1)<<2)
+    //     chunk = n/8 + ((l15&3)>>1) ; addr = r*256 + ((chunk ^ (key<<1)) << 4) + (l15&1)*8
+    const int mc_keyv = (l15 >> 2) | ((g & 1) << 2);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_frag = [&](const char* tile, bool kc, int wsel, int t, int ks) -> bf16x8 {
+        if (kc) {
+            const int row = wsel * 64 + t * 16 + l15;
+            const int chunk = ks * 4 + g;
+            const int off = row * 128 + ((chunk ^ (row & 7)) << 4);
+            return *reinterpret_cast<const bf16x8*>(tile + off);
+        } else {
+            const int ncol = wsel * 64 + t * 16;
+            const int chunk = (ncol >> 3) + ((l15 & 3) >> 1);
+            const int sw = ((chunk ^ (mc_keyv << 1)) << 4) + (l15 & 1) * 8;
+            const int r0 = ks * 32 + 8 * g + (l15 >> 2);
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(tile + r0 * 256 + sw));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(tile + (r0 + 4) * 256 + sw));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* ta = smem + buf * STAGE_BYTES;
+        const char* tb = ta + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = load_frag(ta, A_KC, wm, t, ks);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bfr[t] = load_frag(tb, B_KC, wn, t, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // wave-private slab: f32 [64][64] at smem + wave*16 KiB. C layout of a 16x16 tile:
+    // col = lane&15, row = 4*(lane>>4) + reg.
+    float* slab = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
+    const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
+    const int ccol = n0 + wn * 64 + (lane & 7) * 8;
+    const bool col_ok = ccol < p.N;  // N % 8 == 0 so the 8-wide group is all-in or all-out
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (p.bias != nullptr && col_ok) {
+        if (p.bias_f32) {
+            const float* bp = reinterpret_cast<const float*>(p.bias) + ccol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = bp[e];
+        } else {
+            bf16x8 bv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bias) + ccol);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = bf2f(bv[e]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int lr = it * 8 + (lane >> 3);
+        const int row = m0 + wm * 64 + lr;
+        if (row >= p.M || !col_ok) continue;
+        const float* sp = slab + lr * 64 + (lane & 7) * 8;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t orow = p.cmap(row);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bias8[e]);
+        if (p.scale != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * p.scale);
+        }
+        if (p.act == 1) {
+            if (p.pre_out != nullptr) {
+                bf16x8 pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
+                *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rbf(gelu_tanh_f(v[e]));
+        }
+        if (p.gate != nullptr) {
+            bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * bf2f(gv[e]));
+        }
+        if (p.residual != nullptr) {
+            bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rv[e]));
+        }
+        if (p.out_f32) {
+            float* cp = reinterpret_cast<float*>(p.C) + cz + orow * p.ldc + ccol;
+            if (p.accumulate) {
+                f32x4 o0 = *reinterpret_cast<const f32x4*>(cp);
+                f32x4 o1 = *reinterpret_cast<const f32x4*>(cp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+            }
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + cz + orow * p.ldc + ccol;
+            if (p.accumulate) {
+                bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bf2f(ov[e]);
+            }
+            bf16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x8*>(cp) = ov;
+        }
+    }
+}
+
+}  // namespace
+
+KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
+    KAI0_REQUIRE(d != nullptr, "kai0_gemm_bf16: null descriptor");
+    KAI0_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "kai0_gemm_bf16: empty problem M=%d N=%d K=%d", d->M, d->N,
+                 d->K);
+    KAI0_REQUIRE(d->A && d->B && d->C, "kai0_gemm_bf16: null operand");
+    KAI0_REQUIRE((d->lda % 8) == 0 && (d->ldb % 8) == 0 && (d->ldc % 8) == 0,
+                 "kai0_gemm_bf16: leading dims must be multiples of 8 (lda=%lld ldb=%lld ldc=%lld)",
+                 (long long)d->lda, (long long)d->ldb, (long long)d->ldc);
+    KAI0_REQUIRE((d->N % 8) == 0, "kai0_gemm_bf16: N=%d must be a multiple of 8", d->N);
+    KAI0_REQUIRE((d->K % 8) == 0 || (!d->a_kc && !d->b_kc), "kai0_gemm_bf16: K=%d must be a multiple of 8 for "
+                 "K-contiguous operands", d->K);
+    KAI0_REQUIRE(d->a_kc || (d->M % 8) == 0, "kai0_gemm_bf16: M=%d must be a multiple of 8 when A is [K][M]",
+                 d->M);
+    KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
+                 "kai0_gemm_bf16: operands must be 16-byte aligned");
+    KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
+    const int batch = d->batch > 0 ? d->batch : 1;
+    GemmArgs p;
+    p.A = (const bf16_t*)d->A;
+    p.B = (const bf16_t*)d->B;
+    p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+    p.sA1 = d->sA1; p.sA2 = d->sA2; p.sB1 = d->sB1; p.sB2 = d->sB2; p.sC1 = d->sC1; p.sC2 = d->sC2;
+    p.amap = RowMap{d->a_rpb, d->a_bs, d->a_off};
+    p.bmap = RowMap{d->b_rpb, d->b_bs, d->b_off};
+    p.cmap = RowMap{d->c_rpb, d->c_bs, d->c_off};
+    p.bias = d->bias; p.bias_f32 = d->bias_f32;
+    p.scale = d->scale == 0.0f ? 1.0f : d->scale;
+    p.act = d->act; p.out_f32 = d->out_f32;
+    p.pre_out = (bf16_t*)d->pre_out;
+    p.gate = (const bf16_t*)d->gate; p.gate_rpb = d->gate_rpb; p.gate_ld = d->gate_ld;
+    p.accumulate = d->accumulate;
+    p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
+    p.tiles_m = (d->M + BM - 1) / BM;
+    p.tiles_n = (d->N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, batch, 1), block(256, 1, 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
+    else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+    else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
+    return kai0_check_launch("kai0_gemm_bf16");
+}

@@ -1,0 +1,102 @@
+// gemm_f32.hip — exact-f32 MFMA GEMM (v_mfma_f32_16x16x4_f32) for the f32 islands of the path:
+// SigLIP patch-embed (f32 weights, gemma_pytorch.py:72-75), adaRMS `dense` (f32 by substring match,
+// gemma_pytorch.py:76-78), time MLP and action in/out projections (pi0_pytorch.py:100-105).
+// These are < 1 % of the FLOPs; the kernel is fully strided so forward (x W^T), dgrad (dy W) and
+// wgrad (dy^T x) are the same code with different strides.
+//
+// 64x64x16 block tile, 4 waves (2x2), each wave 32x32 = 2x2 MFMA 16x16x4 tiles, 4 k-steps per tile.
+// LDS image As[k][m] / Bs[k][n] with an 80-float row pitch so the two k-rows a 32-lane group reads
+// hit disjoint banks.
+#include "common.h"
+#include "../../include/kai0hip.h"
+
+namespace {
+
+constexpr int FBM = 64, FBN = 64, FBK = 16, PITCH = 80;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
+                                                       const float* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                       float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                       const float* __restrict__ bias, int accumulate) {
+    __shared__ float As[FBK * PITCH];
+    __shared__ float Bs[FBK * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // loader mapping: pick the memory-fastest index as the thread-fastest one (coalescing)
+    const bool a_kfast = (sak == 1);
+    const bool b_kfast = (sbk == 1);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < K; k0 += FBK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = e * 256 + tid;  // 0..1023
+            int m, k;
+            if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+            float v = 0.f;
+            if (m0 + m < M && k0 + k < K) v = A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak];
+            As[k * PITCH + m] = v;
+            int n, kb;
+            if (b_kfast) { kb = idx & 15; n = idx >> 4; } else { n = idx & 63; kb = idx >> 6; }
+            float w = 0.f;
+            if (n0 + n < N && k0 + kb < K) w = B[(int64_t)(k0 + kb) * sbk + (int64_t)(n0 + n) * sbn];
+            Bs[kb * PITCH + n] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(ks * 4 + g) * PITCH + wm * 32 + t * 16 + l15];
+                b[t] = Bs[(ks * 4 + g) * PITCH + wn * 32 + t * 16 + l15];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C layout: col = lane&15, row = 4*(lane>>4)+reg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 32 + j * 16 + l15;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 32 + i * 16 + 4 * g + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                float* cp = C + (int64_t)row * ldc + col;
+                if (accumulate) v += *cp;
+                *cp = v;
+            }
+        }
+}
+
+}  // namespace
+
+KAI0_API int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                           float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate,
+                           kai0_stream_t stream) {
+    KAI0_REQUIRE(A && B && C, "kai0_gemm_f32: null operand");
+    KAI0_REQUIRE(M > 0 && N > 0 && K > 0, "kai0_gemm_f32: empty problem M=%d N=%d K=%d", M, N, K);
+    dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM, 1), block(256, 1, 1);
+    KAI0_REQUIRE(grid.y <= 65535, "kai0_gemm_f32: M=%d too large for grid.y", M);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M,
+                       N, K, bias, accumulate);
+    return kai0_check_launch("kai0_gemm_f32");
+}

@@ -1,0 +1,460 @@
+// norm.hip — RMSNorm / adaRMSNorm / LayerNorm forward+backward and the column reductions they need.
+// All HBM-bound: one wave64 per row, 16-B (bf16x8) loads, f32 statistics, rows re-read from L2 only.
+// Reference semantics: GemmaRMSNorm (modeling_gemma.py:49-104), nn.LayerNorm in SigLIP
+// (modeling_siglip.py:439-441,756).
+#include "common.h"
+#include "../../include/kai0hip.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // chunks of 8 per lane: D <= 64*8*4 = 2048
+
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+__device__ __forceinline__ void loadf8(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// ------------------------------------------------------------------------------------------ RMSNorm
+// ADA=false: y = bf16((x*rstd)*(1+w));  ADA=true: y = bf16((x*rstd)*(1+scale_b)+shift_b), gate_out=bf16(gate_b)
+template <bool ADA>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ mod, bf16_t* __restrict__ y,
+                                                          bf16_t* __restrict__ gate_out, float* __restrict__ rstd_out,
+                                                          int64_t rows, int rpb, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int nchunk = D >> 3;
+    for (int64_t row = wg; row < rows; row += nw) {
+        const bf16_t* xr = x + row * D;
+        float xv[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                load8(xr + ci * 8, xv[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[c][e] * xv[c][e];
+            }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)D + eps);
+        const float* mrow = nullptr;
+        if constexpr (ADA) mrow = mod + (row / rpb) * (int64_t)(3 * D);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float o[8];
+                if constexpr (ADA) {
+                    float sc[8], sh[8];
+                    loadf8(mrow + ci * 8, sc);
+                    loadf8(mrow + D + ci * 8, sh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] * rstd) * (1.0f + sc[e]) + sh[e];
+                } else {
+                    float wv[8];
+                    loadf8(w + ci * 8, wv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] * rstd) * (1.0f + wv[e]);
+                }
+                store8(y + row * D + ci * 8, o);
+                if constexpr (ADA) {
+                    if (gate_out != nullptr && (row % rpb) == 0) {
+                        float gt[8];
+                        loadf8(mrow + 2 * D + ci * 8, gt);
+                        store8(gate_out + (row / rpb) * (int64_t)D + ci * 8, gt);
+                    }
+                }
+            }
+        }
+        if (lane == 0 && rstd_out != nullptr) rstd_out[row] = rstd;
+    }
+}
+
+// plain RMSNorm backward: dx and per-wave dw partials [gridDim.x*4][D]
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ rstd_in,
+                                                          bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
+                                                          int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int nchunk = D >> 3;
+    float dwa[MAXC][8];
+    float cw[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwa[c][e] = 0.f; cw[c][e] = 0.f; }
+        if (ci < nchunk) {
+            loadf8(w + ci * 8, cw[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cw[c][e] += 1.0f;
+        }
+    }
+    for (int64_t row = wg; row < rows; row += nw) {
+        const float rstd = rstd_in[row];
+        float xh[MAXC][8], dxh[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float dyv[8];
+                load8(dy + row * D + ci * 8, dyv);
+                load8(x + row * D + ci * 8, xh[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[c][e] *= rstd;
+                    dxh[c][e] = dyv[e] * cw[c][e];
+                    s += dxh[c][e] * xh[c][e];
+                    dwa[c][e] += dyv[e] * xh[c][e];
+                }
+            }
+        }
+        s = wave_sum(s) / (float)D;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[c][e] - xh[c][e] * s);
+                store8(dx + row * D + ci * 8, o);
+            }
+        }
+    }
+    float* pr = dw_partial + wg * D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nchunk) {
+            *reinterpret_cast<f32x4*>(pr + ci * 8) = f32x4{dwa[c][0], dwa[c][1], dwa[c][2], dwa[c][3]};
+            *reinterpret_cast<f32x4*>(pr + ci * 8 + 4) = f32x4{dwa[c][4], dwa[c][5], dwa[c][6], dwa[c][7]};
+        }
+    }
+}
+
+// adaRMS backward: one block per batch entry b (rows b*rpb .. b*rpb+rpb-1), thread owns 8 columns.
+//   dx, dmod[b] = [dscale | dshift | dgate] (f32)
+__global__ __launch_bounds__(256) void adarms_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dgate,
+                                                         const bf16_t* __restrict__ x, const float* __restrict__ mod,
+                                                         const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
+                                                         float* __restrict__ dmod, int rpb, int D) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool act = tid * 8 < D;
+    const float* mrow = mod + (int64_t)b * 3 * D;
+    float c1[8], dsc[8], dsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { c1[e] = 0.f; dsc[e] = 0.f; dsh[e] = 0.f; }
+    if (act) {
+        loadf8(mrow + tid * 8, c1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c1[e] += 1.0f;
+    }
+    for (int i = 0; i < rpb; ++i) {
+        const int64_t row = (int64_t)b * rpb + i;
+        const float rstd = rstd_in[row];
+        float xh[8], dxh[8], dyv[8];
+        float s = 0.f;
+        if (act) {
+            load8(dy + row * D + tid * 8, dyv);
+            load8(x + row * D + tid * 8, xh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[e] *= rstd;
+                dxh[e] = dyv[e] * c1[e];
+                s += dxh[e] * xh[e];
+                dsc[e] += dyv[e] * xh[e];
+                dsh[e] += dyv[e];
+            }
+        }
+        s = block_sum<4>(s, red) / (float)D;
+        if (act) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[e] - xh[e] * s);
+            store8(dx + row * D + tid * 8, o);
+        }
+    }
+    if (act) {
+        float* dm = dmod + (int64_t)b * 3 * D;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dm[tid * 8 + e] = dsc[e];
+            dm[D + tid * 8 + e] = dsh[e];
+        }
+        float gt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gt[e] = 0.f;
+        if (dgate != nullptr) load8(dgate + (int64_t)b * D + tid * 8, gt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dm[2 * D + tid * 8 + e] = gt[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------- LayerNorm
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ bsh, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int nchunk = D >> 3;
+    for (int64_t row = wg; row < rows; row += nw) {
+        float xv[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                load8(x + row * D + ci * 8, xv[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += xv[c][e];
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = xv[c][e] - mean;
+                    v += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float wv[8], bv[8], o[8];
+                load8(w + ci * 8, wv);
+                load8(bsh + ci * 8, bv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] - mean) * rstd * wv[e] + bv[e];
+                store8(y + row * D + ci * 8, o);
+            }
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
+// dx and per-wave partials [gridDim.x*4][2*D] = [dw | db]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
+                                                            float* __restrict__ partial, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int nchunk = D >> 3;
+    float dwa[MAXC][8], dba[MAXC][8], wv[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwa[c][e] = 0.f; dba[c][e] = 0.f; wv[c][e] = 0.f; }
+        if (ci < nchunk) load8(w + ci * 8, wv[c]);
+    }
+    for (int64_t row = wg; row < rows; row += nw) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[MAXC][8], dxh[MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float dyv[8];
+                load8(dy + row * D + ci * 8, dyv);
+                load8(x + row * D + ci * 8, xh[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[c][e] = (xh[c][e] - mean) * rstd;
+                    dxh[c][e] = dyv[e] * wv[c][e];
+                    s1 += dxh[c][e];
+                    s2 += dxh[c][e] * xh[c][e];
+                    dwa[c][e] += dyv[e] * xh[c][e];
+                    dba[c][e] += dyv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[c][e] - s1 - xh[c][e] * s2);
+                store8(dx + row * D + ci * 8, o);
+            }
+        }
+    }
+    float* pr = partial + wg * (int64_t)(2 * D);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pr[ci * 8 + e] = dwa[c][e];
+                pr[D + ci * 8 + e] = dba[c][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ column reductions
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int ncols,
+                                                              void* __restrict__ out, int out_f32) {
+    // 64 columns x 4 row-groups per block
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (col < ncols)
+        for (int b = rg; b < blocks; b += 4) s += partial[(int64_t)b * ncols + col];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < ncols) {
+        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        if (out_f32) reinterpret_cast<float*>(out)[col] = t;
+        else reinterpret_cast<bf16_t*>(out)[col] = f2bf(t);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int64_t M, int N, int64_t ld,
+                                                     float* __restrict__ scratch) {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc * 8 >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
+        float v[8];
+        load8(dy + m * ld + cc * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    float* sp = scratch + (int64_t)blockIdx.y * N + cc * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sp[e] = acc[e];
+}
+
+inline int norm_grid(int64_t rows) {
+    int64_t b = (rows + 3) / 4;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define CHECK_D(name, D) KAI0_REQUIRE((D) % 8 == 0 && (D) > 0 && (D) <= 2048, name ": D=%d must be a multiple of 8, <= 2048", (D))
+
+KAI0_API int kai0_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int D, float eps,
+                              kai0_stream_t stream) {
+    CHECK_D("kai0_rmsnorm_fwd", D);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<false>), dim3(norm_grid(rows)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, w, (const float*)nullptr, (bf16_t*)y, (bf16_t*)nullptr, rstd, rows, 1, D, eps);
+    return kai0_check_launch("kai0_rmsnorm_fwd");
+}
+
+KAI0_API int kai0_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, void* dx,
+                              float* dw_partial, int dw_blocks, int64_t rows, int D, kai0_stream_t stream) {
+    CHECK_D("kai0_rmsnorm_bwd", D);
+    KAI0_REQUIRE(dw_blocks > 0, "kai0_rmsnorm_bwd: dw_blocks must be > 0");
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(dw_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, w, rstd, (bf16_t*)dx, dw_partial, rows, D);
+    return kai0_check_launch("kai0_rmsnorm_bwd");
+}
+
+KAI0_API int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gate_out, float* rstd, int64_t rows,
+                             int rows_per_batch, int D, float eps, kai0_stream_t stream) {
+    CHECK_D("kai0_adarms_fwd", D);
+    KAI0_REQUIRE(rows_per_batch > 0, "kai0_adarms_fwd: rows_per_batch must be > 0");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<true>), dim3(norm_grid(rows)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const float*)nullptr, mod, (bf16_t*)y, (bf16_t*)gate_out, rstd, rows,
+                       rows_per_batch, D, eps);
+    return kai0_check_launch("kai0_adarms_fwd");
+}
+
+KAI0_API int kai0_adarms_bwd(const void* dy, const void* dgate, const void* x, const float* mod, const float* rstd,
+                             void* dx, float* dmod, int64_t rows, int rows_per_batch, int D, kai0_stream_t stream) {
+    CHECK_D("kai0_adarms_bwd", D);
+    KAI0_REQUIRE(rows_per_batch > 0 && rows % rows_per_batch == 0, "kai0_adarms_bwd: rows %% rows_per_batch != 0");
+    const int B = (int)(rows / rows_per_batch);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(adarms_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)dgate, (const bf16_t*)x, mod, rstd, (bf16_t*)dx, dmod, rows_per_batch, D);
+    return kai0_check_launch("kai0_adarms_bwd");
+}
+
+KAI0_API int kai0_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                                int64_t rows, int D, float eps, kai0_stream_t stream) {
+    CHECK_D("kai0_layernorm_fwd", D);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(norm_grid(rows)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, D, eps);
+    return kai0_check_launch("kai0_layernorm_fwd");
+}
+
+KAI0_API int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                                void* dx, float* dwb_partial, int dwb_blocks, int64_t rows, int D,
+                                kai0_stream_t stream) {
+    CHECK_D("kai0_layernorm_bwd", D);
+    KAI0_REQUIRE(dwb_blocks > 0, "kai0_layernorm_bwd: dwb_blocks must be > 0");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(dwb_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dwb_partial, rows, D);
+    return kai0_check_launch("kai0_layernorm_bwd");
+}
+
+KAI0_API int kai0_reduce_partials(const float* partial, int blocks, int ncols, void* out, int out_f32,
+                                  kai0_stream_t stream) {
+    KAI0_REQUIRE(blocks > 0 && ncols > 0, "kai0_reduce_partials: empty");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
+                       blocks, ncols, out, out_f32);
+    return kai0_check_launch("kai0_reduce_partials");
+}
+
+KAI0_API int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
+                              void* out, int out_f32, kai0_stream_t stream) {
+    KAI0_REQUIRE(N % 8 == 0 && ld % 8 == 0, "kai0_colsum_bf16: N=%d and ld must be multiples of 8", N);
+    KAI0_REQUIRE(scratch_blocks > 0, "kai0_colsum_bf16: scratch_blocks must be > 0");
+    int sb = scratch_blocks;
+    if ((int64_t)sb > M) sb = (int)M;
+    dim3 grid((N / 8 + 255) / 256, sb, 1);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, M, N, ld, scratch);
+    int rc = kai0_check_launch("kai0_colsum_bf16");
+    if (rc) return rc;
+    return kai0_reduce_partials(scratch, sb, N, out, out_f32, stream);
+}

@@ -1,0 +1,115 @@
+// optim.hip — gradient-norm clip + fused AdamW over flat shards (train_pytorch.py:469-475,557-561;
+// optimizer.py:15-85).  HBM-bound: 16 B/param of f32 state (master, m, v read+write) + grad + bf16 copy.
+#include "common.h"
+#include "../../include/kai0hip.h"
+
+namespace {
+
+template <bool GF32>
+__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    if constexpr (GF32) {
+        const float* p = reinterpret_cast<const float*>(g);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(p + i * 4);
+            acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        if (blockIdx.x == 0)
+            for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += p[i] * p[i];
+    } else {
+        const bf16_t* p = reinterpret_cast<const bf16_t*>(g);
+        const int64_t n8 = n >> 3;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(p + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(v[e]);
+                acc += f * f;
+            }
+        }
+        if (blockIdx.x == 0)
+            for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += 256) {
+                const float f = bf2f(p[i]);
+                acc += f * f;
+            }
+    }
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef,
+                                 float* __restrict__ norm_out) {
+    const float nrm = sqrtf(sumsq[0]);
+    if (norm_out) norm_out[0] = nrm;
+    const float c = max_norm / (nrm + 1e-6f);
+    coef[0] = c < 1.0f ? c : 1.0f;
+}
+
+template <bool GF32, bool PF32>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                    const void* __restrict__ grad, void* __restrict__ param, int64_t n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2, const float* __restrict__ coef) {
+    const float cc = coef ? coef[0] : 1.0f;
+    const float inv_bc1 = 1.0f / bc1;
+    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float g = GF32 ? reinterpret_cast<const float*>(grad)[i] : bf2f(reinterpret_cast<const bf16_t*>(grad)[i]);
+        g *= cc;
+        float p = master[i];
+        float mi = m[i] * b1 + (1.0f - b1) * g;
+        float vi = v[i] * b2 + (1.0f - b2) * g * g;
+        // torch.optim.AdamW: p *= 1 - lr*wd ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+        p = p * (1.0f - lr * wd);
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p = p - (lr * inv_bc1) * (mi / denom);
+        master[i] = p;
+        m[i] = mi;
+        v[i] = vi;
+        if (PF32) reinterpret_cast<float*>(param)[i] = p;
+        else reinterpret_cast<bf16_t*>(param)[i] = f2bf(p);
+    }
+}
+
+inline int opt_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+KAI0_API int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    KAI0_REQUIRE(((uintptr_t)g % 16) == 0, "kai0_sumsq: unaligned buffer");
+    const int grid = opt_grid(g_f32 ? n / 4 + 1 : n / 8 + 1);
+    if (g_f32) hipLaunchKernelGGL((sumsq_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    else hipLaunchKernelGGL((sumsq_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    return kai0_check_launch("kai0_sumsq");
+}
+
+KAI0_API int kai0_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, kai0_stream_t stream) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
+    return kai0_check_launch("kai0_clip_coef");
+}
+
+KAI0_API int kai0_adamw(float* master, float* m, float* v, const void* grad, int grad_f32, void* model_param,
+                        int param_f32, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bias_c1,
+                        float bias_c2, const float* clip_coef, kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    KAI0_REQUIRE(master && m && v && grad && model_param, "kai0_adamw: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(opt_grid(n)), block(256);
+#define LAUNCH(G, P)                                                                                              \
+    hipLaunchKernelGGL((adamw_kernel<G, P>), grid, block, 0, s, master, m, v, grad, model_param, n, lr, beta1, beta2, \
+                       eps, wd, bias_c1, bias_c2, clip_coef)
+    if (grad_f32 && param_f32) LAUNCH(true, true);
+    else if (grad_f32) LAUNCH(true, false);
+    else if (param_f32) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return kai0_check_launch("kai0_adamw");
+}
