@@ -91,6 +91,8 @@ typedef struct kai0_gemm_desc {
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
+/* sizeof(kai0_gemm_desc) as compiled: lets a foreign-language binding verify its struct mirror */
+int kai0_gemm_desc_size(void);
 
 /* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C)
  * Replaces the f32 islands: patch-embed conv as im2col GEMM (modeling_siglip.py:220-226), adaRMS
@@ -160,7 +162,10 @@ int kai0_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, kai0_str
 /* y = silu(x), f32 (time MLP, pi0_pytorch.py:289-297) */
 int kai0_silu_fwd_f32(const float* x, float* y, int64_t n, kai0_stream_t stream);
 int kai0_silu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, kai0_stream_t stream);
-/* gated residual backward (modeling_gemma.py:209-227): for out = x + y*gate[b]:
+/* gated residual (modeling_gemma.py:209-227): out = bf16( x + bf16(y * gate[row / rows_per_batch]) ) */
+int kai0_gated_fwd(const void* x, const void* y, const void* gate, void* out, int64_t rows, int rows_per_batch,
+                   int D, kai0_stream_t stream);
+/* gated residual backward: for out = x + y*gate[b]:
  *   dy = bf16(dout * gate[b]);  dgate[b][c] = bf16( sum_rows_in_b dout*y )  (f32 accumulation) */
 int kai0_gated_bwd(const void* dout, const void* y, const void* gate, void* dy, void* dgate, int64_t rows,
                    int rows_per_batch, int D, kai0_stream_t stream);
@@ -194,7 +199,10 @@ int kai0_add_pos_cast(const float* x, const float* pos, void* out, int64_t rows,
  * x_t = t*noise + (1-t)*a ; u_t = noise - a                         (f32, [B][HA]) */
 int kai0_flow_mix(const float* noise, const float* actions, const float* time, float* x_t, float* u_t, int B,
                   int HA, kai0_stream_t stream);
-/* loss = (u - v)^2 ; dv = -2 (u - v) * gscale                         (f32) */
+/* time embedding (pi0_pytorch.py:25-42): out[b] = [sin(w_i t_b) | cos(w_i t_b)], f64 math, f32 result */
+int kai0_time_sincos(const float* time, float* out, int B, int dim, double min_period, double max_period,
+                     kai0_stream_t stream);
+/* loss = (u - v)^2 ; dv = -2 (u - v) * dloss                          (f32) */
 int kai0_mse_fwd(const float* u, const float* v, float* loss, int64_t n, kai0_stream_t stream);
 int kai0_mse_bwd(const float* u, const float* v, const float* dloss, float* dv, int64_t n,
                  kai0_stream_t stream);

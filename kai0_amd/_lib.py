@@ -1,0 +1,125 @@
+"""ctypes binding of libkai0hip.so — the C-ABI boundary (include/kai0hip.h).
+
+The product path has NO fallback: if the shared library is missing, or a call is attempted without a GPU,
+this module raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libkai0hip.so"
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_i64 = C.c_int64
+c_f = C.c_float
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `kai0_gemm_desc` (include/kai0hip.h)."""
+
+    _fields_ = [
+        ("A", c_p), ("B", c_p), ("C", c_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_kc", C.c_int32), ("b_kc", C.c_int32),
+        ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
+        ("batch", C.c_int32), ("batch_inner", C.c_int32),
+        ("sA1", c_i64), ("sA2", c_i64), ("sB1", c_i64), ("sB2", c_i64), ("sC1", c_i64), ("sC2", c_i64),
+        ("a_rpb", C.c_int32), ("b_rpb", C.c_int32), ("c_rpb", C.c_int32), ("_pad0", C.c_int32),
+        ("a_bs", c_i64), ("a_off", c_i64), ("b_bs", c_i64), ("b_off", c_i64), ("c_bs", c_i64), ("c_off", c_i64),
+        ("bias", c_p), ("bias_f32", C.c_int32), ("scale", c_f),
+        ("act", C.c_int32), ("out_f32", C.c_int32),
+        ("pre_out", c_p), ("gate", c_p), ("gate_rpb", C.c_int32), ("accumulate", C.c_int32),
+        ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64), ("sR1", c_i64), ("sR2", c_i64),
+    ]  # fmt: skip
+
+
+# name -> argtypes (every function returns int except where noted)
+_PROTOS: dict[str, list] = {
+    "kai0_abi_version": [],
+    "kai0_gemm_desc_size": [],
+    "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
+    "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
+    "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_p],
+    "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
+    "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p],
+    "kai0_adarms_fwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p],
+    "kai0_adarms_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_layernorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
+    "kai0_layernorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p],
+    "kai0_reduce_partials": [c_p, c_i, c_i, c_p, c_i, c_p],
+    "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
+    "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
+    "kai0_softmax_mask_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
+    "kai0_softmax_bwd": [c_p, c_p, c_p, c_i64, c_i, c_i64, c_f, c_p],
+    "kai0_geglu_fwd": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_geglu_bwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "kai0_gelu_bwd": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_silu_fwd_f32": [c_p, c_p, c_i64, c_p],
+    "kai0_silu_bwd_f32": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_gated_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_gated_bwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_embed_gather": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i64, c_i64, c_i64, c_p],
+    "kai0_embed_grad": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i64, c_i64, c_i64, c_p],
+    "kai0_cast_f32_to_bf16": [c_p, c_p, c_i64, c_p],
+    "kai0_cast_bf16_to_f32": [c_p, c_p, c_i64, c_p],
+    "kai0_add_bf16": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_add_f32": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_copy_rows_bf16": [c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p],
+    "kai0_patch_im2col": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "kai0_add_pos_cast": [c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_time_sincos": [c_p, c_p, c_i, c_i, C.c_double, C.c_double, c_p],
+    "kai0_flow_mix": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "kai0_mse_fwd": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_mse_bwd": [c_p, c_p, c_p, c_p, c_i64, c_p],
+    "kai0_euler_step": [c_p, c_p, c_f, c_i64, c_p],
+    "kai0_sumsq": [c_p, c_i, c_i64, c_p, c_p],
+    "kai0_clip_coef": [c_p, c_f, c_p, c_p, c_p],
+    "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
+}  # fmt: skip
+
+EXPORTED_SYMBOLS = ("kai0_last_error", *_PROTOS.keys())
+
+_lib = None
+
+
+class Kai0HipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libkai0hip.so (built in-tree by `python -m kai0_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = pathlib.Path(os.environ.get("KAI0_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise Kai0HipError(
+            f"{path} not found: the HIP extension is not built. Run `python -m kai0_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(str(path))
+    lib.kai0_last_error.restype = C.c_char_p
+    lib.kai0_last_error.argtypes = []
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = c_i
+        fn.argtypes = args
+    if lib.kai0_gemm_desc_size() != C.sizeof(GemmDesc):
+        raise Kai0HipError(
+            f"kai0_gemm_desc layout mismatch: C {lib.kai0_gemm_desc_size()} B vs ctypes {C.sizeof(GemmDesc)} B"
+        )
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an entry point and raise with kai0_last_error() on a non-zero return."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise Kai0HipError(f"{name} failed ({rc}): {lib.kai0_last_error().decode()}")

@@ -1,0 +1,30 @@
+"""Build libkai0hip.so in-tree: `python -m kai0_amd.build` (hipcc cross-compiles gfx950 without a GPU)."""
+
+from __future__ import annotations
+
+import pathlib
+import subprocess
+import sys
+
+HERE = pathlib.Path(__file__).resolve().parent
+SRC = ["runtime.hip", "gemm_bf16.hip", "gemm_f32.hip", "norm.hip", "elementwise.hip", "optim.hip"]
+OUT = HERE / "lib" / "libkai0hip.so"
+
+
+def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
+    srcs = [HERE / "csrc" / s for s in SRC]
+    deps = srcs + [HERE / "csrc" / "common.h", HERE.parent / "include" / "kai0hip.h"]
+    if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return OUT
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           *map(str, srcs), "-o", str(OUT)]  # fmt: skip
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

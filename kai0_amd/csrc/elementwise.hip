@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
 
 // ------------------------------------------------------------------------------------- masked softmax
 constexpr int SM_MAXC = 8;  // ld <= 4096
-__global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* __restrict__ scores, bf16_t* __restrict__ probs,
+__global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* scores, bf16_t* probs,
                                                                const int32_t* __restrict__ qcode,
                                                                const int32_t* __restrict__ kcode, int B, int Sq, int H,
                                                                int Sk, int64_t ld, int64_t bstride, int q0,
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* __r
     }
 }
 
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ probs, const bf16_t* __restrict__ dprobs,
-                                                          bf16_t* __restrict__ dscores, int64_t rows, int Sk, int64_t ld,
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ probs, const bf16_t* dprobs,
+                                                          bf16_t* dscores, int64_t rows, int Sk, int64_t ld,
                                                           float scale) {
     const int lane = threadIdx.x & 63;
     const int nchunk = (int)(ld >> 3);
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 }
 
 // --------------------------------------------------------------------------------------------- GeGLU
-__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u,
-                                                        bf16_t* __restrict__ h, int64_t n8) {
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* g, const bf16_t* __restrict__ u,
+                                                        bf16_t* h, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         float gv[8], uv[8], o[8];
         ld8(g + i * 8, gv);
@@ -224,6 +224,25 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__
         const float v = x[i];
         const float sg = 1.0f / (1.0f + expf(-v));
         dx[i] = dy[i] * (sg * (1.0f + v * (1.0f - sg)));
+    }
+}
+
+// gated residual forward (modeling_gemma.py:209-227): out = bf16(x + bf16(y * gate[b]))
+__global__ __launch_bounds__(256) void gated_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                        const bf16_t* __restrict__ gate, bf16_t* __restrict__ out,
+                                                        int64_t rows, int rpb, int D) {
+    const int d8 = D >> 3;
+    const int64_t total = rows * d8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / d8;
+        const int c0 = (int)(i - row * d8) * 8;
+        float xv[8], yv[8], gt[8];
+        ld8(x + row * D + c0, xv);
+        ld8(y + row * D + c0, yv);
+        ld8(gate + (row / rpb) * D + c0, gt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] += rbf(yv[e] * gt[e]);
+        st8(out + row * D + c0, xv);
     }
 }
 
@@ -379,6 +398,24 @@ __global__ __launch_bounds__(256) void add_pos_cast_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------ flow matching
+// create_sinusoidal_pos_embedding (pi0_pytorch.py:25-42): f64 arithmetic, cast to f32 at the end.
+// out[b] = [sin(s_i * t_b) | cos(s_i * t_b)], s_i = 2*pi / (min * (max/min)^(i/(n-1))), i < n = dim/2.
+__global__ __launch_bounds__(256) void time_sincos_kernel(const float* __restrict__ time, float* __restrict__ out, int B,
+                                                          int dim, double min_period, double max_period) {
+    const int half = dim >> 1;
+    const int total = B * half;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / half, j = i - b * half;
+        // torch.linspace(0, 1, half, float64): start + step*j for j < half/2, end - step*(half-1-j) otherwise
+        const double step = half > 1 ? 1.0 / (double)(half - 1) : 0.0;
+        const double frac = (j < half / 2) ? step * (double)j : 1.0 - step * (double)(half - 1 - j);
+        const double period = min_period * pow(max_period / min_period, frac);
+        const double scaling = 1.0 / period * 2.0 * 3.141592653589793;
+        const double x = scaling * (double)time[b];
+        out[(int64_t)b * dim + j] = (float)sin(x);
+        out[(int64_t)b * dim + half + j] = (float)cos(x);
+    }
+}
 __global__ __launch_bounds__(256) void flow_mix_kernel(const float* __restrict__ noise, const float* __restrict__ act,
                                                        const float* __restrict__ time, float* __restrict__ xt,
                                                        float* __restrict__ ut, int B, int HA) {
@@ -476,6 +513,14 @@ KAI0_API int kai0_silu_bwd_f32(const float* dy, const float* x, float* dx, int64
     hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), dy, x, dx, n);
     return kai0_check_launch("kai0_silu_bwd_f32");
 }
+KAI0_API int kai0_gated_fwd(const void* x, const void* y, const void* gate, void* out, int64_t rows,
+                            int rows_per_batch, int D, kai0_stream_t stream) {
+    KAI0_REQUIRE(D % 8 == 0 && rows_per_batch > 0, "kai0_gated_fwd: bad D=%d / rows_per_batch=%d", D, rows_per_batch);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gated_fwd_kernel, dim3(ew_grid(rows * (D / 8), 256)), dim3(256), 0, S_(stream), (const bf16_t*)x,
+                       (const bf16_t*)y, (const bf16_t*)gate, (bf16_t*)out, rows, rows_per_batch, D);
+    return kai0_check_launch("kai0_gated_fwd");
+}
 KAI0_API int kai0_gated_bwd(const void* dout, const void* y, const void* gate, void* dy, void* dgate, int64_t rows,
                             int rows_per_batch, int D, kai0_stream_t stream) {
     KAI0_REQUIRE(D % 8 == 0, "kai0_gated_bwd: D must be a multiple of 8");
@@ -547,6 +592,14 @@ KAI0_API int kai0_add_pos_cast(const float* x, const float* pos, void* out, int6
     hipLaunchKernelGGL(add_pos_cast_kernel, dim3(ew_grid(rows * D, 256)), dim3(256), 0, S_(stream), x, pos,
                        (bf16_t*)out, rows, n_pos, D);
     return kai0_check_launch("kai0_add_pos_cast");
+}
+KAI0_API int kai0_time_sincos(const float* time, float* out, int B, int dim, double min_period, double max_period,
+                              kai0_stream_t stream) {
+    KAI0_REQUIRE(dim % 2 == 0, "kai0_time_sincos: dimension (%d) must be divisible by 2", dim);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(time_sincos_kernel, dim3(ew_grid((int64_t)B * dim / 2, 256)), dim3(256), 0, S_(stream), time, out,
+                       B, dim, min_period, max_period);
+    return kai0_check_launch("kai0_time_sincos");
 }
 KAI0_API int kai0_flow_mix(const float* noise, const float* actions, const float* time, float* x_t, float* u_t, int B,
                            int HA, kai0_stream_t stream) {

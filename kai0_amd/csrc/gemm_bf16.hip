@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int ccol = n0 + wn * 64 + (lane & 7) * 8;
-    const bool col_ok = ccol < p.N;  // N % 8 == 0 so the 8-wide group is all-in or all-out
+    // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
+    // zero-filled) and are stored into the row padding the host guarantees (ldc >= round_up(N, 8)).
+    const bool col_ok = ccol < ((p.N + 7) & ~7);
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -342,7 +344,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE((d->lda % 8) == 0 && (d->ldb % 8) == 0 && (d->ldc % 8) == 0,
                  "kai0_gemm_bf16: leading dims must be multiples of 8 (lda=%lld ldb=%lld ldc=%lld)",
                  (long long)d->lda, (long long)d->ldb, (long long)d->ldc);
-    KAI0_REQUIRE((d->N % 8) == 0, "kai0_gemm_bf16: N=%d must be a multiple of 8", d->N);
+    KAI0_REQUIRE((d->N % 8) == 0 || (d->b_kc && d->ldc >= ((d->N + 7) & ~7) && !d->bias && !d->gate && !d->residual &&
+                                     !d->pre_out && !d->accumulate),
+                 "kai0_gemm_bf16: N=%d not a multiple of 8 needs b_kc, padded C rows and a plain epilogue", d->N);
     KAI0_REQUIRE((d->K % 8) == 0 || (!d->a_kc && !d->b_kc), "kai0_gemm_bf16: K=%d must be a multiple of 8 for "
                  "K-contiguous operands", d->K);
     KAI0_REQUIRE(d->a_kc || (d->M % 8) == 0, "kai0_gemm_bf16: M=%d must be a multiple of 8 when A is [K][M]",

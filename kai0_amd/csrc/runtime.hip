@@ -25,6 +25,7 @@ int kai0_check_launch(const char* what) {
 
 KAI0_API const char* kai0_last_error(void) { return g_err; }
 KAI0_API int kai0_abi_version(void) { return 1; }
+KAI0_API int kai0_gemm_desc_size(void) { return (int)sizeof(kai0_gemm_desc); }
 
 KAI0_API int kai0_device_info(int device, int* n_cu, int* lds_bytes, char* arch_name64) {
     hipDeviceProp_t prop;

@@ -1,0 +1,242 @@
+"""Action-chunk inference engine: prefix pass into a static KV cache + Euler denoise loop, captured as one
+hipGraph (pi0_pytorch.py:375-461; gemma_pytorch.py:102-125; modeling_gemma.py:282-329).
+
+MI355X-first choices:
+  * static, pre-allocated KV cache [layers][B, S_ld, HD]: the prefix pass writes rows [0, P), every denoise
+    step overwrites rows [P, P+H) in place — no `torch.cat([cache, new])`, no DynamicCache;
+  * projection GEMMs write straight into the padded q / K / V buffers (row-remap epilogue) and o_proj reads
+    the attention output through the same remap: no concat/split copies;
+  * o_proj / down_proj fuse the expert's gated residual (x + y*gate) into the GEMM epilogue;
+  * the time schedule of the Euler loop is fixed (t = 1, 1+dt, ...), so the time-MLP conditioning and all
+    37 adaRMS modulations for ALL steps are computed once per call as M = steps*B row GEMMs
+    (0.46 GB of f32 `dense` weights are read once instead of once per step);
+  * the last prefix layer stops after its K/V projection — nothing reads its attention/MLP output;
+  * the whole call (SigLIP -> prefix -> all denoise steps) is recorded once into a hipGraph
+    (torch.cuda.CUDAGraph on ROCm is hipGraph) and replayed per request: no per-op Python or launch cost.
+"""
+
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .ops import BF16, F32, gemm, round_up
+
+logger = logging.getLogger("kai0_amd")
+
+
+def euler_times(num_steps: int) -> list[float]:
+    """The t values visited by `while time >= -dt/2` with f32 accumulation (pi0_pytorch.py:401-419)."""
+    dt = np.float32(-1.0 / num_steps)
+    t = np.float32(1.0)
+    out = []
+    while t >= -dt / 2:
+        out.append(float(t))
+        t = np.float32(t + dt)
+    return out
+
+
+class InferenceEngine:
+    def __init__(self, model, batch: int, n_lang: int, n_cam: int):
+        self.model = model
+        pe = model.paligemma_with_expert
+        self.pe = pe
+        self.B, self.T, self.ncam = batch, n_lang, n_cam
+        self.n_img = pe.paligemma.model.vision_tower.vision_model.embeddings.num_patches
+        self.P = n_cam * self.n_img + n_lang
+        self.Hs = model.config.action_horizon
+        self.A = model.config.action_dim
+        self.S = self.P + self.Hs
+        self.S_ld = round_up(self.S, 8)
+        cfg = pe.vlm_cfg
+        self.H, self.HD = cfg.num_heads, cfg.head_dim
+        self.Dp, self.De = cfg.width, pe.exp_cfg.width
+        self.L = cfg.depth
+        dev = next(model.parameters()).device
+        self.dev = dev
+        B, S_ld, H, HD = self.B, self.S_ld, self.H, self.HD
+        self.k_cache = [torch.zeros((B, S_ld, HD), dtype=BF16, device=dev) for _ in range(self.L)]
+        self.v_cache = [torch.zeros((B, S_ld, HD), dtype=BF16, device=dev) for _ in range(self.L)]
+        self.q_buf = torch.zeros((B, S_ld, H * HD), dtype=BF16, device=dev)
+        self.att_buf = torch.zeros((B, S_ld, H * HD), dtype=BF16, device=dev)
+        self.use_graph = os.environ.get("KAI0_INFER_GRAPH", "1") != "0"
+        self._times_dev = {}
+        self._graph = None
+        self._graph_steps = None
+        self._static_in = None
+        self._static_out = None
+
+    def compatible(self, batch, n_lang, n_cam):
+        return (batch, n_lang, n_cam) == (self.B, self.T, self.ncam)
+
+    # ---------------------------------------------------------------------------------------------- attention
+    def _attend(self, l: int, q0: int, Sq: int, Sk: int, qcode, kcode):
+        """masked MQA over the static buffers for query rows [q0, q0+Sq) against key rows [0, Sk)."""
+        B, S_ld, H, HD = self.B, self.S_ld, self.H, self.HD
+        M = Sq * H
+        scores = torch.empty((B, M, S_ld), dtype=BF16, device=self.dev)
+        gemm(self.q_buf, self.k_cache[l], scores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=B,
+             sA=(S_ld * H * HD, 0), sB=(S_ld * HD, 0), sC=(M * S_ld, 0), scale=HD**-0.5, a_off_elems=q0 * H * HD)  # fmt: skip
+        _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), scores.data_ptr(), qcode.data_ptr(), kcode.data_ptr(), B,
+                  Sq, H, Sk, S_ld, M * S_ld, q0, qcode.stride(0), kcode.stride(0), ops._stream())  # fmt: skip
+        gemm(scores, self.v_cache[l], self.att_buf, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD,
+             batch=B, sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD)  # fmt: skip
+
+    def _proj_into(self, x, lin, dst, rows_pb: int, row0: int, width: int):
+        """dst[b, row0 + r, :width] = (x @ W^T)[b*rows_pb + r]  — GEMM epilogue row remap, no copy."""
+        M, K = x.shape
+        gemm(x, lin.weight, dst, M=M, N=width, K=K, lda=K, ldb=K, ldc=width, c_map=(rows_pb, self.S_ld, row0))
+
+    def _oproj(self, lin, rows_pb: int, row0: int, residual, gate=None):
+        """y = att_buf[b, row0 + r] @ Wo^T (+gate) + residual, reading the padded buffer through the A row remap."""
+        B, H, HD = self.B, self.H, self.HD
+        M = B * rows_pb
+        N = lin.weight.shape[0]
+        out = torch.empty((M, N), dtype=BF16, device=self.dev)
+        gemm(self.att_buf, lin.weight, out, M=M, N=N, K=H * HD, lda=H * HD, ldb=H * HD, ldc=N,
+             a_map=(rows_pb, self.S_ld, row0), residual=residual, ldr=N, gate=gate, gate_rpb=rows_pb, gate_ld=N)  # fmt: skip
+        return out
+
+    # ------------------------------------------------------------------------------------------------ passes
+    def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks):
+        model, pe = self.model, self.pe
+        B, P, Hs = self.B, self.P, self.Hs
+        prefix, ppad, patt = model.embed_prefix(images, img_masks, lang_tokens, lang_masks)
+        dev = prefix.device
+        spad = torch.ones((B, Hs), dtype=torch.bool, device=dev)
+        satt = torch.zeros((B, Hs), dtype=torch.bool, device=dev)
+        satt[:, 0] = True
+        from .model import build_mask_codes
+
+        qcode, kcode, pos = build_mask_codes(torch.cat([ppad, spad], dim=1), torch.cat([patt, satt], dim=1))
+        self.qcode, self.kcode, self.pos = qcode, kcode, pos
+        self.pos_prefix = pos[:, :P].contiguous()
+        self.pos_suffix = pos[:, P:].contiguous()
+        lm = pe.paligemma.model.language_model
+        inv_freq = lm.inv_freq
+        H, HD, S_ld = self.H, self.HD, self.S_ld
+        xp = prefix.reshape(B * P, self.Dp)
+        for l, layer in enumerate(lm.layers):
+            hp = ops.rmsnorm(xp, layer.input_layernorm.weight, layer.input_layernorm.eps)
+            at = layer.self_attn
+            self._proj_into(hp, at.k_proj, self.k_cache[l], P, 0, HD)
+            self._proj_into(hp, at.v_proj, self.v_cache[l], P, 0, HD)
+            ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
+            if l == self.L - 1:
+                break  # nothing consumes the last prefix layer's attention / MLP output
+            self._proj_into(hp, at.q_proj, self.q_buf, P, 0, H * HD)
+            ops.rope_(self.q_buf, self.pos_prefix, inv_freq, B, P, S_ld, 0, H, HD)
+            self._attend(l, 0, P, P, qcode, kcode)
+            xp = self._oproj(at.o_proj, P, 0, residual=xp)
+            hp = ops.rmsnorm(xp, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
+            g = ops.linear_fwd(hp, layer.mlp.gate_proj.weight)
+            u = ops.linear_fwd(hp, layer.mlp.up_proj.weight)
+            _lib.call("kai0_geglu_fwd", g.data_ptr(), u.data_ptr(), g.data_ptr(), g.numel(), ops._stream())
+            xp = ops.linear_fwd(g, layer.mlp.down_proj.weight, residual=xp)
+
+    def _modulations(self, times: list[float]):
+        """time embedding -> time MLP -> adaRMS `dense` for every step at once (rows = step*B + b)."""
+        model, B, De = self.model, self.B, self.De
+        n = len(times)
+        tt = self._times_dev[tuple(times)]
+        te = torch.empty((n * B, De), dtype=F32, device=self.dev)
+        _lib.call("kai0_time_sincos", tt.data_ptr(), te.data_ptr(), n * B, De, 4e-3, 4.0, ops._stream())
+        x = ops.silu_f32(ops.linear_f32(te, model.time_mlp_in.weight, model.time_mlp_in.bias))
+        cond = ops.silu_f32(ops.linear_f32(x, model.time_mlp_out.weight, model.time_mlp_out.bias))
+        ex = self.pe.gemma_expert.model
+        mods = []
+        for layer in ex.layers:
+            m1 = ops.linear_f32(cond, layer.input_layernorm.dense.weight, layer.input_layernorm.dense.bias)
+            m2 = ops.linear_f32(cond, layer.post_attention_layernorm.dense.weight, layer.post_attention_layernorm.dense.bias)
+            mods.append((m1, m2))
+        mf = ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
+        return mods, mf
+
+    def _denoise_step(self, x_t, step: int, mods, mf):
+        model, pe = self.model, self.pe
+        B, P, Hs, De = self.B, self.P, self.Hs, self.De
+        H, HD, S_ld = self.H, self.HD, self.S_ld
+        ex = pe.gemma_expert.model
+        inv_freq = pe.paligemma.model.language_model.inv_freq
+        a = ops.linear_f32(x_t.view(B * Hs, self.A), model.action_in_proj.weight, model.action_in_proj.bias)
+        xs = ops.cast(a, BF16)
+        rows = slice(step * B, (step + 1) * B)
+        for l, layer in enumerate(ex.layers):
+            m1, m2 = mods[l][0][rows], mods[l][1][rows]
+            hs, gate1 = ops.adarms(xs, m1, Hs, layer.input_layernorm.eps)
+            at = layer.self_attn
+            self._proj_into(hs, at.q_proj, self.q_buf, Hs, P, H * HD)
+            self._proj_into(hs, at.k_proj, self.k_cache[l], Hs, P, HD)
+            self._proj_into(hs, at.v_proj, self.v_cache[l], Hs, P, HD)
+            ops.rope_(self.q_buf, self.pos_suffix, inv_freq, B, Hs, S_ld, P, H, HD)
+            ops.rope_(self.k_cache[l], self.pos_suffix, inv_freq, B, Hs, S_ld, P, 1, HD)
+            self._attend(l, P, Hs, P + Hs, self.qcode, self.kcode)
+            xs = self._oproj(at.o_proj, Hs, P, residual=xs, gate=gate1)
+            hs, gate2 = ops.adarms(xs, m2, Hs, layer.post_attention_layernorm.eps)
+            g = ops.linear_fwd(hs, layer.mlp.gate_proj.weight)
+            u = ops.linear_fwd(hs, layer.mlp.up_proj.weight)
+            _lib.call("kai0_geglu_fwd", g.data_ptr(), u.data_ptr(), g.data_ptr(), g.numel(), ops._stream())
+            xs = ops.linear_fwd(g, layer.mlp.down_proj.weight, residual=xs, gate=gate2, gate_rpb=Hs)
+        out, _ = ops.adarms(xs, mf[rows], Hs, ex.norm.eps)
+        v = ops.linear_f32(ops.cast(out, F32), model.action_out_proj.weight, model.action_out_proj.bias)
+        return v.view(B, Hs, self.A)
+
+    def _run(self, images, img_masks, lang_tokens, lang_masks, noise, num_steps: int):
+        times = euler_times(num_steps)
+        dt = float(np.float32(-1.0 / num_steps))
+        if tuple(times) not in self._times_dev:  # H2D copy: must happen outside graph capture (warm-up run)
+            self._times_dev[tuple(times)] = torch.tensor(times, dtype=F32).repeat_interleave(self.B).to(self.dev)
+        self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
+        mods, mf = self._modulations(times)
+        x_t = noise.clone().contiguous()
+        for step in range(len(times)):
+            v_t = self._denoise_step(x_t, step, mods, mf)
+            ops.euler_step_(x_t, v_t, dt)
+        return x_t
+
+    # -------------------------------------------------------------------------------------------------- API
+    @torch.no_grad()
+    def sample_actions(self, images, img_masks, lang_tokens, lang_masks, noise, num_steps: int = 10):
+        if not self.use_graph:
+            return self._run(images, img_masks, lang_tokens, lang_masks, noise, num_steps)
+        if self._graph is None or self._graph_steps != num_steps:
+            self._capture(images, img_masks, lang_tokens, lang_masks, noise, num_steps)
+        if self._graph is None:  # capture refused: stay on eager HIP launches
+            return self._run(images, img_masks, lang_tokens, lang_masks, noise, num_steps)
+        si = self._static_in
+        for dst, src in zip(si["images"], images, strict=True):
+            dst.copy_(src)
+        for dst, src in zip(si["img_masks"], img_masks, strict=True):
+            dst.copy_(src)
+        si["lang_tokens"].copy_(lang_tokens)
+        si["lang_masks"].copy_(lang_masks)
+        si["noise"].copy_(noise)
+        self._graph.replay()
+        return self._static_out.clone()
+
+    def _capture(self, images, img_masks, lang_tokens, lang_masks, noise, num_steps: int):
+        si = {
+            "images": [im.clone().contiguous() for im in images],
+            "img_masks": [m.clone() for m in img_masks],
+            "lang_tokens": lang_tokens.clone().contiguous(),
+            "lang_masks": lang_masks.clone().contiguous(),
+            "noise": noise.clone().contiguous(),
+        }
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
+                self._run(si["images"], si["img_masks"], si["lang_tokens"], si["lang_masks"], si["noise"], num_steps)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._run(si["images"], si["img_masks"], si["lang_tokens"], si["lang_masks"], si["noise"], num_steps)
+            self._graph, self._graph_steps, self._static_in, self._static_out = graph, num_steps, si, out
+        except Exception as e:  # noqa: BLE001 - capture problems must not take serving down
+            logger.warning("hipGraph capture failed (%s); running eager HIP launches", e)
+            self._graph = None
+            self.use_graph = False

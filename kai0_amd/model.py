@@ -1,0 +1,523 @@
+"""PI0Pytorch-shaped pi0.5 model whose arithmetic runs on the MI355X HIP kernels (libkai0hip.so).
+
+Boundary mirrored: `PI0Pytorch(config)`, `.forward(observation, actions, noise=None, time=None)
+-> loss [B, H, A]`, `.sample_actions(device, observation, noise=None, num_steps=10) -> [B, H, A]`,
+`.gradient_checkpointing_enable()`, `.paligemma_with_expert.to_bfloat16_for_selected_params(...)`, and an
+nn.Module parameter tree whose state_dict keys / shapes / dtypes equal the reference's
+(pi0_pytorch.py:84-461, gemma_pytorch.py:12-281; key list in SURVEY.md §8a16).
+
+Layout choices (MI355X-first, not a translation of the HF modules):
+  * activations are flat [B*S, D] bf16 matrices so every Linear is one large MFMA GEMM (M = B*S rows);
+  * the 3 cameras go through SigLIP as one batch of 3B images;
+  * the joint attention folds the 8 query heads of the single KV head into the GEMM M dimension
+    (Q viewed as [S*8, 256] per sample), so QK^T / PV are plain batched GEMMs with K/V read once per sample;
+  * the prefix-LM mask is never materialised (no [S,S] tensor): two int32 codes per token feed the softmax;
+  * 288 GB HBM: full-batch activations of all 45 layers stay resident, so rematerialisation is off by default
+    (`gradient_checkpointing_enable()` keeps the reference API and turns it on).
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .config import Pi0Config, SiglipConfig, get_config
+from .preprocessing import IMAGE_KEYS, preprocess_observation
+
+BF16, F32 = torch.bfloat16, torch.float32
+INT_MAX = 2**31 - 1
+logger = logging.getLogger("kai0_amd")
+
+
+# ------------------------------------------------------------------------------------- parameter containers
+class Linear(nn.Module):
+    """nn.Linear-shaped parameter holder (weight [out, in], optional bias)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.normal_(self.weight, std=0.02)
+        if bias:
+            nn.init.zeros_(self.bias)
+
+
+class Embedding(nn.Module):
+    def __init__(self, num: int, dim: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num, dim))
+        nn.init.normal_(self.weight, std=0.02)
+
+
+class Conv2dParams(nn.Module):
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.normal_(self.weight, std=0.02)
+
+
+class LayerNormParams(nn.Module):
+    def __init__(self, dim: int, eps: float):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class GemmaRMSNorm(nn.Module):
+    """Parameters of GemmaRMSNorm (modeling_gemma.py:49-64): `weight` (plain) or `dense` (adaRMS)."""
+
+    def __init__(self, dim: int, eps: float = 1e-6, cond_dim: int | None = None):
+        super().__init__()
+        self.eps, self.dim, self.cond_dim = eps, dim, cond_dim
+        if cond_dim is not None:
+            self.dense = Linear(cond_dim, dim * 3, bias=True)
+            nn.init.zeros_(self.dense.weight)
+        else:
+            self.weight = nn.Parameter(torch.zeros(dim))
+            self.dense = None
+
+
+class GemmaMLP(nn.Module):
+    def __init__(self, width: int, mlp_dim: int):
+        super().__init__()
+        self.gate_proj = Linear(width, mlp_dim, bias=False)
+        self.up_proj = Linear(width, mlp_dim, bias=False)
+        self.down_proj = Linear(mlp_dim, width, bias=False)
+
+
+class GemmaAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.head_dim = cfg.head_dim
+        self.num_heads = cfg.num_heads
+        self.num_key_value_groups = cfg.num_heads // cfg.num_kv_heads
+        self.scaling = cfg.head_dim**-0.5
+        self.q_proj = Linear(cfg.width, cfg.num_heads * cfg.head_dim, bias=False)
+        self.k_proj = Linear(cfg.width, cfg.num_kv_heads * cfg.head_dim, bias=False)
+        self.v_proj = Linear(cfg.width, cfg.num_kv_heads * cfg.head_dim, bias=False)
+        self.o_proj = Linear(cfg.num_heads * cfg.head_dim, cfg.width, bias=False)
+
+
+class GemmaDecoderLayer(nn.Module):
+    def __init__(self, cfg, cond_dim):
+        super().__init__()
+        self.self_attn = GemmaAttention(cfg)
+        self.mlp = GemmaMLP(cfg.width, cfg.mlp_dim)
+        self.input_layernorm = GemmaRMSNorm(cfg.width, cond_dim=cond_dim)
+        self.post_attention_layernorm = GemmaRMSNorm(cfg.width, cond_dim=cond_dim)
+
+
+class GemmaModel(nn.Module):
+    def __init__(self, cfg, vocab: int, use_adarms: bool, with_embed: bool):
+        super().__init__()
+        self.cfg = cfg
+        cond_dim = cfg.width if use_adarms else None
+        self.embed_tokens = Embedding(vocab, cfg.width) if with_embed else None
+        self.layers = nn.ModuleList([GemmaDecoderLayer(cfg, cond_dim) for _ in range(cfg.depth)])
+        self.norm = GemmaRMSNorm(cfg.width, cond_dim=cond_dim)
+        self.gradient_checkpointing = False
+        # ROPE_INIT_FUNCTIONS["default"] (transformers 4.53.2): 1 / 10000^(arange(0, hd, 2) / hd), f32
+        hd = cfg.head_dim
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.int64).to(dtype=torch.float) / hd))
+        self.register_buffer("inv_freq", inv, persistent=False)
+
+
+class GemmaForCausalLM(nn.Module):
+    def __init__(self, cfg, vocab: int, use_adarms: bool):
+        super().__init__()
+        self.model = GemmaModel(cfg, vocab, use_adarms, with_embed=False)
+        # never used by the forward (263 M dead parameters) but part of the reference state dict (§8a16)
+        self.lm_head = Linear(cfg.width, vocab, bias=False)
+
+
+class SiglipVisionEmbeddings(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.patch_size = c.patch_size
+        self.patch_embedding = Conv2dParams(3, c.hidden_size, c.patch_size)
+        self.num_patches = (c.image_size // c.patch_size) ** 2
+        self.position_embedding = Embedding(self.num_patches, c.hidden_size)
+
+
+class SiglipAttention(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.num_heads = c.num_heads
+        self.head_dim = c.hidden_size // c.num_heads
+        self.k_proj = Linear(c.hidden_size, c.hidden_size)
+        self.v_proj = Linear(c.hidden_size, c.hidden_size)
+        self.q_proj = Linear(c.hidden_size, c.hidden_size)
+        self.out_proj = Linear(c.hidden_size, c.hidden_size)
+
+
+class SiglipMLP(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.fc1 = Linear(c.hidden_size, c.intermediate_size)
+        self.fc2 = Linear(c.intermediate_size, c.hidden_size)
+
+
+class SiglipEncoderLayer(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.layer_norm1 = LayerNormParams(c.hidden_size, c.layer_norm_eps)
+        self.self_attn = SiglipAttention(c)
+        self.layer_norm2 = LayerNormParams(c.hidden_size, c.layer_norm_eps)
+        self.mlp = SiglipMLP(c)
+
+
+class SiglipEncoder(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.layers = nn.ModuleList([SiglipEncoderLayer(c) for _ in range(c.num_layers)])
+
+
+class SiglipVisionTransformer(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.embeddings = SiglipVisionEmbeddings(c)
+        self.encoder = SiglipEncoder(c)
+        self.post_layernorm = LayerNormParams(c.hidden_size, c.layer_norm_eps)
+
+
+class SiglipVisionModel(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.vision_model = SiglipVisionTransformer(c)
+        self.gradient_checkpointing = False
+
+
+class PaliGemmaMultiModalProjector(nn.Module):
+    def __init__(self, c: SiglipConfig):
+        super().__init__()
+        self.linear = Linear(c.hidden_size, c.projection_dim, bias=True)
+
+
+class PaliGemmaModel(nn.Module):
+    def __init__(self, cfg, vocab: int, sc: SiglipConfig):
+        super().__init__()
+        self.vision_tower = SiglipVisionModel(sc)
+        self.multi_modal_projector = PaliGemmaMultiModalProjector(sc)
+        self.language_model = GemmaModel(cfg, vocab, use_adarms=False, with_embed=True)
+
+
+class PaliGemmaForConditionalGeneration(nn.Module):
+    def __init__(self, cfg, vocab: int, sc: SiglipConfig):
+        super().__init__()
+        self.model = PaliGemmaModel(cfg, vocab, sc)
+        self.lm_head = Linear(cfg.width, vocab, bias=False)
+        self.lm_head.weight = self.model.language_model.embed_tokens.weight  # tied, as post_init does
+
+    @property
+    def language_model(self):
+        return self.model.language_model
+
+    @property
+    def vision_tower(self):
+        return self.model.vision_tower
+
+
+KEEP_F32_SELECTORS = (  # gemma_pytorch.py:72-79 (substring match; also catches the adaRMS `dense` layers)
+    "vision_tower.vision_model.embeddings.patch_embedding.weight",
+    "vision_tower.vision_model.embeddings.patch_embedding.bias",
+    "vision_tower.vision_model.embeddings.position_embedding.weight",
+    "input_layernorm",
+    "post_attention_layernorm",
+    "model.norm",
+)
+
+
+# ---------------------------------------------------------------------------------------- compute helpers
+def _lin(x, mod: Linear, residual=None, act=0):
+    return ops.linear(x, mod.weight, mod.bias, residual, act)
+
+
+def build_mask_codes(pad_masks: torch.Tensor, att_masks: torch.Tensor):
+    """Integer restatement of make_att_2d_masks (pi0_pytorch.py:52-81): token j is visible from token i iff
+    cumsum(att)[j] <= cumsum(att)[i] and both are valid.  Encoded as kcode[j] <= qcode[i] with
+    qcode = pad ? cumsum : -1 and kcode = pad ? cumsum : INT_MAX (bit-exact, no [S,S] tensor).
+    Also returns position_ids = cumsum(pad) - 1 (pi0_pytorch.py:343)."""
+    cum = torch.cumsum(att_masks.to(torch.int32), dim=1)
+    pad = pad_masks.to(torch.bool)
+    qcode = torch.where(pad, cum, torch.full_like(cum, -1)).to(torch.int32).contiguous()
+    kcode = torch.where(pad, cum, torch.full_like(cum, INT_MAX)).to(torch.int32).contiguous()
+    pos = (torch.cumsum(pad.to(torch.int32), dim=1) - 1).to(torch.int32).contiguous()
+    return qcode, kcode, pos
+
+
+class PaliGemmaWithExpertModel(nn.Module):
+    """Parameter tree + kernels-backed compute of gemma_pytorch.py:12-281."""
+
+    def __init__(self, vlm_config, action_expert_config, use_adarms=None, precision: str = "bfloat16",
+                 vocab: int = 257_152, siglip: SiglipConfig | None = None):  # fmt: skip
+        super().__init__()
+        if use_adarms is None:
+            use_adarms = [False, False]
+        if use_adarms[0]:
+            raise NotImplementedError("adaRMS on the PaliGemma tower is not part of pi0.5")
+        self.vlm_cfg, self.exp_cfg = vlm_config, action_expert_config
+        self.siglip_cfg = siglip or SiglipConfig()
+        self.paligemma = PaliGemmaForConditionalGeneration(vlm_config, vocab, self.siglip_cfg)
+        self.gemma_expert = GemmaForCausalLM(action_expert_config, vocab, use_adarms[1])
+        self.remat = False
+        self.to_bfloat16_for_selected_params(precision)
+
+    def to_bfloat16_for_selected_params(self, precision: str = "bfloat16"):
+        """gemma_pytorch.py:63-83. The HIP path computes in bf16; "float32" storage is accepted for loading
+        f32 checkpoints (model_arithmetic saves f32) but must be followed by a "bfloat16" call before compute."""
+        if precision == "bfloat16":
+            self.to(dtype=BF16)
+        elif precision == "float32":
+            self.to(dtype=F32)
+            return
+        else:
+            raise ValueError(f"Invalid precision: {precision}")
+        for name, param in self.named_parameters():
+            if any(sel in name for sel in KEEP_F32_SELECTORS):
+                param.data = param.data.to(dtype=F32)
+
+    # ---- SigLIP + projector (modeling_siglip.py:763-796; modeling_paligemma.py:232-245) -------------------
+    def embed_image(self, image: torch.Tensor) -> torch.Tensor:
+        """image f32 [N, 3, HW, HW] in [-1, 1] -> bf16 [N, n_patches, projection_dim]."""
+        n = image.shape[0]
+        vt = self.paligemma.model.vision_tower.vision_model
+        sc = self.siglip_cfg
+        S = vt.embeddings.num_patches
+        NH, HD = sc.num_heads, sc.hidden_size // sc.num_heads
+        emb = vt.embeddings
+        x = ops.patch_embed(image.contiguous(), emb.patch_embedding.weight, emb.patch_embedding.bias,
+                            emb.position_embedding.weight, sc.patch_size)  # fmt: skip
+
+        def layer_fn(x, layer):
+            h = ops.layernorm(x, layer.layer_norm1.weight, layer.layer_norm1.bias, layer.layer_norm1.eps)
+            at = layer.self_attn
+            q, k, v = _lin(h, at.q_proj), _lin(h, at.k_proj), _lin(h, at.v_proj)
+            a = ops.siglip_attention(q, k, v, n, S, NH, HD)
+            x = _lin(a, at.out_proj, residual=x)
+            h = ops.layernorm(x, layer.layer_norm2.weight, layer.layer_norm2.bias, layer.layer_norm2.eps)
+            f = _lin(h, layer.mlp.fc1, act=1)
+            return _lin(f, layer.mlp.fc2, residual=x)
+
+        for layer in vt.encoder.layers:
+            x = self._maybe_remat(layer_fn, x, layer)
+        x = ops.layernorm(x, vt.post_layernorm.weight, vt.post_layernorm.bias, vt.post_layernorm.eps)
+        x = _lin(x, self.paligemma.model.multi_modal_projector.linear)
+        return x.view(n, S, -1)
+
+    def embed_language_tokens(self, tokens: torch.Tensor) -> torch.Tensor:
+        """Raw embedding lookup (gemma_pytorch.py:88-89), [B, T] int64 -> bf16 [B, T, D]."""
+        table = self.paligemma.model.language_model.embed_tokens.weight
+        return ops.embed(table, tokens, 1.0).view(*tokens.shape, -1)
+
+    def _maybe_remat(self, fn, *args):
+        if self.remat and self.training and torch.is_grad_enabled():
+            return torch.utils.checkpoint.checkpoint(fn, *args, use_reentrant=False, preserve_rng_state=False)
+        return fn(*args)
+
+    # ---- joint, layer-interleaved forward (gemma_pytorch.py:126-279) ---------------------------------------
+    def forward_joint(self, prefix: torch.Tensor, suffix: torch.Tensor, qcode, kcode, pos, cond: torch.Tensor,
+                      B: int, P: int, Hs: int) -> torch.Tensor:  # fmt: skip
+        """prefix bf16 [B*P, Dp], suffix bf16 [B*Hs, De], cond f32 [B, De] -> suffix output after the expert's
+        final adaRMS norm, bf16 [B*Hs, De].  (The prefix's final norm has no consumer in training.)"""
+        lm, ex = self.paligemma.model.language_model, self.gemma_expert.model
+        cfg = self.vlm_cfg
+        H, HD = cfg.num_heads, cfg.head_dim
+        inv_freq = lm.inv_freq
+
+        def layer_fn(xp, xs, lp, le):
+            hp = ops.rmsnorm(xp, lp.input_layernorm.weight, lp.input_layernorm.eps)
+            mod1 = ops.linear_f32(cond, le.input_layernorm.dense.weight, le.input_layernorm.dense.bias)
+            hs, gate1 = ops.adarms(xs, mod1, Hs, le.input_layernorm.eps)
+            ap, ae = lp.self_attn, le.self_attn
+            qkv = (_lin(hp, ap.q_proj), _lin(hp, ap.k_proj), _lin(hp, ap.v_proj),
+                   _lin(hs, ae.q_proj), _lin(hs, ae.k_proj), _lin(hs, ae.v_proj))  # fmt: skip
+            att_p, att_s = ops.joint_attention(pos, qcode, kcode, inv_freq, H, HD, (P, Hs), qkv)
+            # prefix: o_proj + residual fused in the GEMM epilogue, then RMSNorm -> GeGLU MLP -> residual
+            xp = _lin(att_p, ap.o_proj, residual=xp)
+            hp = ops.rmsnorm(xp, lp.post_attention_layernorm.weight, lp.post_attention_layernorm.eps)
+            hp = ops.geglu(_lin(hp, lp.mlp.gate_proj), _lin(hp, lp.mlp.up_proj))
+            xp = _lin(hp, lp.mlp.down_proj, residual=xp)
+            # suffix (action expert): gated residuals (modeling_gemma.py:209-227)
+            xs = ops.gated_residual(xs, _lin(att_s, ae.o_proj), gate1, Hs)
+            mod2 = ops.linear_f32(cond, le.post_attention_layernorm.dense.weight, le.post_attention_layernorm.dense.bias)
+            hs, gate2 = ops.adarms(xs, mod2, Hs, le.post_attention_layernorm.eps)
+            hs = ops.geglu(_lin(hs, le.mlp.gate_proj), _lin(hs, le.mlp.up_proj))
+            xs = ops.gated_residual(xs, _lin(hs, le.mlp.down_proj), gate2, Hs)
+            return xp, xs
+
+        xp, xs = prefix, suffix
+        for lp, le in zip(lm.layers, ex.layers, strict=True):
+            xp, xs = self._maybe_remat(layer_fn, xp, xs, lp, le)
+        modf = ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
+        out, _ = ops.adarms(xs, modf, Hs, ex.norm.eps)
+        return out
+
+
+class PI0Pytorch(nn.Module):
+    """Drop-in for openpi's `PI0Pytorch` (pi0_pytorch.py:84-461), pi0.5 branch."""
+
+    def __init__(self, config: Pi0Config):
+        super().__init__()
+        self.config = config
+        self.pi05 = config.pi05
+        if not self.pi05:
+            raise NotImplementedError("only the pi0.5 branch (pi05=True) is on the hot path")
+        vlm = get_config(config.paligemma_variant)
+        exp = get_config(config.action_expert_variant)
+        siglip = getattr(config, "siglip", None) or SiglipConfig()
+        self.paligemma_with_expert = PaliGemmaWithExpertModel(
+            vlm, exp, use_adarms=[False, True], precision=config.dtype, vocab=getattr(config, "vocab_size", 257_152),
+            siglip=siglip,
+        )  # fmt: skip
+        self.action_in_proj = Linear(config.action_dim, exp.width)
+        self.action_out_proj = Linear(exp.width, config.action_dim)
+        self.time_mlp_in = Linear(exp.width, exp.width)
+        self.time_mlp_out = Linear(exp.width, exp.width)
+        self.gradient_checkpointing_enabled = False
+        # the reference hard-codes train=True (random crop/rotate/colour) in forward (pi0_pytorch.py:318);
+        # parity tests switch it off and inject noise/time.
+        self.train_augmentation = True
+        self._engine = None
+
+    # ---- reference API ------------------------------------------------------------------------------------
+    def gradient_checkpointing_enable(self):
+        """pi0_pytorch.py:126-133. Activations fit in 288 GB HBM, so this is optional here; when enabled each
+        layer is rematerialised in backward exactly like the reference's per-layer checkpoint."""
+        self.gradient_checkpointing_enabled = True
+        self.paligemma_with_expert.remat = True
+        pe = self.paligemma_with_expert
+        pe.paligemma.model.language_model.gradient_checkpointing = True
+        pe.paligemma.model.vision_tower.gradient_checkpointing = True
+        pe.gemma_expert.model.gradient_checkpointing = True
+        logger.info("Enabled gradient checkpointing for PI0Pytorch model")
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing_enabled = False
+        self.paligemma_with_expert.remat = False
+        pe = self.paligemma_with_expert
+        pe.paligemma.model.language_model.gradient_checkpointing = False
+        pe.paligemma.model.vision_tower.gradient_checkpointing = False
+        pe.gemma_expert.model.gradient_checkpointing = False
+
+    def is_gradient_checkpointing_enabled(self):
+        return self.gradient_checkpointing_enabled
+
+    def sample_noise(self, shape, device):
+        return torch.normal(mean=0.0, std=1.0, size=shape, dtype=F32, device=device)
+
+    def sample_time(self, bsize, device):
+        a = torch.as_tensor(1.5, dtype=F32, device=device)
+        b = torch.as_tensor(1.0, dtype=F32, device=device)
+        t = torch.distributions.Beta(a, b).sample((bsize,))
+        return (t * 0.999 + 0.001).to(dtype=F32, device=device)
+
+    def _preprocess_observation(self, observation, *, train=True):
+        res = self.paligemma_with_expert.siglip_cfg.image_size
+        obs = preprocess_observation(observation, train=train, image_resolution=(res, res))
+        return (list(obs.images.values()), list(obs.image_masks.values()), obs.tokenized_prompt,
+                obs.tokenized_prompt_mask, obs.state)  # fmt: skip
+
+    # ---- embeddings ---------------------------------------------------------------------------------------
+    def embed_prefix(self, images, img_masks, lang_tokens, lang_masks):
+        """pi0_pytorch.py:186-235 -> (embs bf16 [B, P, D], pad_masks bool [B, P], att_masks bool [B, P])."""
+        pe = self.paligemma_with_expert
+        B = lang_tokens.shape[0]
+        ncam = len(images)
+        feats = pe.embed_image(torch.cat(images, dim=0))  # one SigLIP pass over ncam*B images
+        n_img = feats.shape[1]
+        D = feats.shape[2]
+        lang = ops.embed(pe.paligemma.model.language_model.embed_tokens.weight, lang_tokens, ops.sqrt_scale(D))
+        T = lang_tokens.shape[1]
+        P = ncam * n_img + T
+        embs = PrefixAssembleFn.apply(feats.reshape(ncam * B * n_img, D), lang, B, ncam, n_img, T)
+        pad = torch.cat([m[:, None].expand(B, n_img) for m in img_masks] + [lang_masks.to(torch.bool)], dim=1)
+        att = torch.zeros((B, P), dtype=torch.bool, device=pad.device)
+        return embs.view(B, P, D), pad, att
+
+    def embed_suffix(self, state, noisy_actions, timestep):
+        """pi0_pytorch.py:237-314 (pi0.5): -> (action embs f32 [B, H, De], pad, att, adarms_cond f32 [B, De])."""
+        B, Hs, A = noisy_actions.shape
+        De = self.action_in_proj.out_features
+        te = torch.empty((B, De), dtype=F32, device=noisy_actions.device)
+        _lib.call("kai0_time_sincos", timestep.contiguous().data_ptr(), te.data_ptr(), B, De, 4e-3, 4.0, ops._stream())
+        x = ops.silu_f32(ops.linear_f32(te, self.time_mlp_in.weight, self.time_mlp_in.bias))
+        cond = ops.silu_f32(ops.linear_f32(x, self.time_mlp_out.weight, self.time_mlp_out.bias))
+        a = ops.linear_f32(noisy_actions.reshape(B * Hs, A).contiguous(), self.action_in_proj.weight, self.action_in_proj.bias)
+        pad = torch.ones((B, Hs), dtype=torch.bool, device=a.device)
+        att = torch.zeros((B, Hs), dtype=torch.bool, device=a.device)
+        att[:, 0] = True
+        return a.view(B, Hs, De), pad, att, cond
+
+    # ---- training forward ---------------------------------------------------------------------------------
+    def forward(self, observation, actions, noise=None, time=None) -> torch.Tensor:
+        """pi0_pytorch.py:316-373 -> un-reduced flow-matching loss f32 [B, H, A]."""
+        images, img_masks, lang_tokens, lang_masks, state = self._preprocess_observation(
+            observation, train=self.train_augmentation
+        )
+        if noise is None:
+            noise = self.sample_noise(actions.shape, actions.device)
+        if time is None:
+            time = self.sample_time(actions.shape[0], actions.device)
+        actions = actions.to(F32).contiguous()
+        x_t, u_t = ops.flow_mix(noise.to(F32).contiguous(), actions, time.to(F32).contiguous())
+        prefix, ppad, patt = self.embed_prefix(images, img_masks, lang_tokens, lang_masks)
+        suffix, spad, satt, cond = self.embed_suffix(state, x_t, time)
+        B, P, Dp = prefix.shape
+        Hs, De = suffix.shape[1], suffix.shape[2]
+        qcode, kcode, pos = build_mask_codes(torch.cat([ppad, spad], dim=1), torch.cat([patt, satt], dim=1))
+        suffix_bf = ops.cast_ag(suffix.reshape(B * Hs, De), BF16)
+        out = self.paligemma_with_expert.forward_joint(prefix.reshape(B * P, Dp), suffix_bf, qcode, kcode, pos, cond, B, P, Hs)
+        out32 = ops.cast_ag(out, F32)
+        v_t = ops.linear_f32(out32, self.action_out_proj.weight, self.action_out_proj.bias)
+        loss = ops.mse_loss(u_t.view(B * Hs, -1), v_t)
+        return loss.view(B, Hs, -1)
+
+    # ---- inference ----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_actions(self, device, observation, noise=None, num_steps=10) -> torch.Tensor:
+        """pi0_pytorch.py:375-419: prefix pass into a static KV cache, then `num_steps` Euler steps."""
+        from .infer import InferenceEngine
+
+        bsize = observation.state.shape[0]
+        if noise is None:
+            noise = self.sample_noise((bsize, self.config.action_horizon, self.config.action_dim), device)
+        images, img_masks, lang_tokens, lang_masks, state = self._preprocess_observation(observation, train=False)
+        if self._engine is None or not self._engine.compatible(bsize, lang_tokens.shape[1], len(images)):
+            self._engine = InferenceEngine(self, bsize, lang_tokens.shape[1], len(images))
+        return self._engine.sample_actions(images, img_masks, lang_tokens, lang_masks, noise.to(F32), num_steps)
+
+
+class PrefixAssembleFn(torch.autograd.Function):
+    """Concatenate [cam0 | cam1 | ... | language] along the sequence axis into the flat prefix [B*P, D]
+    (pi0_pytorch.py:228).  feats are laid out image-major: image index = cam*B + b."""
+
+    @staticmethod
+    def forward(ctx, feats, lang, B: int, ncam: int, n_img: int, T: int):
+        D = feats.shape[1]
+        P = ncam * n_img + T
+        out = torch.empty((B * P, D), dtype=BF16, device=feats.device)
+        for c in range(ncam):
+            src = feats[c * B * n_img :]
+            ops._copy_rows(src, out, B, n_img, D, n_img * D, 0, D, P * D, c * n_img, D)
+        ops._copy_rows(lang, out, B, T, D, T * D, 0, D, P * D, ncam * n_img, D)
+        ctx.dims = (B, ncam, n_img, T, D, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, ncam, n_img, T, D, P = ctx.dims
+        dout = dout.contiguous()
+        dfeats = torch.empty((ncam * B * n_img, D), dtype=BF16, device=dout.device)
+        dlang = torch.empty((B * T, D), dtype=BF16, device=dout.device)
+        for c in range(ncam):
+            dst = dfeats[c * B * n_img :]
+            ops._copy_rows(dout, dst, B, n_img, D, P * D, c * n_img, D, n_img * D, 0, D)
+        ops._copy_rows(dout, dlang, B, T, D, P * D, ncam * n_img, D, T * D, 0, D)
+        return dfeats, dlang, None, None, None, None

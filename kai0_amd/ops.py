@@ -1,0 +1,721 @@
+"""Host-side operator layer over the C-ABI (include/kai0hip.h).
+
+Two levels:
+  * `raw.*`-style functions (`gemm`, `rmsnorm_fwd`, ...) — 1:1 over the C entry points: they take torch CUDA
+    tensors, pass `data_ptr()` + the current HIP stream, allocate nothing but their outputs.
+  * `torch.autograd.Function` shims (`LinearFn`, `RMSNormFn`, ...) that pair each forward kernel with its
+    backward kernels so the model stays an ordinary nn.Module with `.grad` semantics — which is what
+    kai0's model_arithmetic (arithmetic_torch.py:197-218) and train_pytorch.py:547-567 rely on.
+
+PyTorch is used here for device memory, streams and autograd bookkeeping only; all arithmetic on the path
+is done by libkai0hip.so.  There is deliberately no CPU / eager fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+NORM_PARTIAL_BLOCKS = 128  # blocks (x4 waves) producing dw partials in norm backward
+COLSUM_BLOCKS = 256
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.Kai0HipError(f"{name}: expected a CUDA (HIP) tensor; the product path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(
+    A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, a_kc: bool = True,
+    b_kc: bool = True, lda: int, ldb: int, ldc: int, batch: int = 1, batch_inner: int = 1,
+    sA=(0, 0), sB=(0, 0), sC=(0, 0), a_map=None, b_map=None, c_map=None, bias: torch.Tensor | None = None,
+    scale: float = 1.0, act: int = 0, pre_out: torch.Tensor | None = None, gate: torch.Tensor | None = None,
+    gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
+    accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0,
+) -> torch.Tensor:  # fmt: skip
+    """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
+    pointer (for column slices such as a head inside a fused projection)."""
+    d = GemmDesc()
+    d.A = A.data_ptr() + 2 * a_off_elems
+    d.B = B.data_ptr() + 2 * b_off_elems
+    out_f32 = out.dtype == F32
+    d.C = out.data_ptr() + (4 if out_f32 else 2) * c_off_elems
+    d.M, d.N, d.K = M, N, K
+    d.a_kc, d.b_kc = int(a_kc), int(b_kc)
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.batch, d.batch_inner = batch, batch_inner
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    if a_map:
+        d.a_rpb, d.a_bs, d.a_off = a_map
+    if b_map:
+        d.b_rpb, d.b_bs, d.b_off = b_map
+    if c_map:
+        d.c_rpb, d.c_bs, d.c_off = c_map
+    if bias is not None:
+        d.bias = bias.data_ptr()
+        d.bias_f32 = int(bias.dtype == F32)
+    d.scale = scale
+    d.act = act
+    d.out_f32 = int(out_f32)
+    d.pre_out = _p(pre_out)
+    if gate is not None:
+        d.gate = gate.data_ptr()
+        d.gate_rpb = gate_rpb
+        d.gate_ld = gate_ld
+    if residual is not None:
+        d.residual = residual.data_ptr()
+        d.ldr = ldr
+        d.sR1, d.sR2 = sR
+    d.accumulate = int(accumulate)
+    _lib.call("kai0_gemm_bf16", C.byref(d), _stream())
+    return out
+
+
+def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None, gate_rpb=0, out=None):
+    """y = epilogue(x @ w.T) for flat bf16 x [M,K], w [N,K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    pre = torch.empty((M, N), dtype=BF16, device=x.device) if want_pre else None
+    gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, pre_out=pre, residual=residual, ldr=N,
+         gate=gate, gate_rpb=gate_rpb, gate_ld=N)  # fmt: skip
+    return (out, pre) if want_pre else out
+
+
+def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=False):
+    _lib.call("kai0_gemm_f32", A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, out.data_ptr(), out.stride(0), M, N, K,
+              _p(bias), int(accumulate), _stream())  # fmt: skip
+    return out
+
+
+# ----------------------------------------------------------------------------------------- autograd shims
+class LinearFn(torch.autograd.Function):
+    """bf16 Linear with fused bias / GELU-tanh / residual epilogue (nn.Linear + F.gelu + `x + y`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, act: int):
+        _chk(x, BF16, "linear.x")
+        _chk(w, BF16, "linear.w")
+        need_pre = act == 1 and (x.requires_grad or w.requires_grad)
+        r = linear_fwd(x, w, bias, residual, act, want_pre=need_pre)
+        out, pre = r if need_pre else (r, None)
+        ctx.save_for_backward(x, w, pre)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.has_res = residual is not None
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, pre = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dres = dout if ctx.has_res else None
+        dy = dout
+        if ctx.act == 1:
+            dy = torch.empty_like(dout)
+            _lib.call("kai0_gelu_bwd", dout.data_ptr(), pre.data_ptr(), dy.data_ptr(), dout.numel(), _stream())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=BF16, device=x.device)
+            # dx[M,K] = dy[M,N] @ w[N,K]  (A K-contig over N; B stored [N][K] = [contraction][cols])
+            gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=BF16, device=x.device)
+            # dw[N,K] = dy[M,N]^T @ x[M,K]  (both stored [contraction][cols])
+            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((N,), dtype=ctx.bias_dtype, device=x.device)
+            scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=x.device)
+            _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, N, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
+                      int(ctx.bias_dtype == F32), _stream())  # fmt: skip
+        return dx, dw, db, dres, None
+
+
+def linear(x, w, bias=None, residual=None, act=0):
+    return LinearFn.apply(x, w, bias, residual, act)
+
+
+class LinearF32Fn(torch.autograd.Function):
+    """f32 Linear (exact-f32 MFMA): adaRMS dense, time MLP, action in/out projections."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _chk(x, F32, "linear_f32.x")
+        _chk(w, F32, "linear_f32.w")
+        M, K = x.shape
+        N = w.shape[0]
+        out = torch.empty((M, N), dtype=F32, device=x.device)
+        gemm_f32(x, K, 1, w, 1, K, out, M, N, K, bias=bias)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=F32, device=x.device)
+            gemm_f32(dout, N, 1, w, K, 1, dx, M, K, N)  # dx[m,k] = sum_n dout[m,n] w[n,k]
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=F32, device=x.device)
+            gemm_f32(dout, 1, N, x, K, 1, dw, N, K, M)  # dw[n,k] = sum_m dout[m,n] x[m,k]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((N,), dtype=F32, device=x.device)
+            ones = torch.ones((1, M), dtype=F32, device=x.device)
+            gemm_f32(ones, M, 1, dout, N, 1, db.view(1, N), 1, N, M)  # db[n] = sum_m dout[m,n]
+        return dx, dw, db
+
+
+def linear_f32(x, w, bias=None):
+    return LinearF32Fn.apply(x, w, bias)
+
+
+class RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps: float):
+        _chk(x, BF16, "rmsnorm.x")
+        _chk(w, F32, "rmsnorm.w")
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        rstd = torch.empty((rows,), dtype=F32, device=x.device)
+        _lib.call("kai0_rmsnorm_fwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, D, eps, _stream())
+        ctx.save_for_backward(x, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, D = x.shape
+        dx = torch.empty_like(x)
+        nb = NORM_PARTIAL_BLOCKS
+        part = torch.empty((nb * 4, D), dtype=F32, device=x.device)
+        _lib.call("kai0_rmsnorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                  part.data_ptr(), nb, rows, D, _stream())  # fmt: skip
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((D,), dtype=F32, device=x.device)
+            _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, D, dw.data_ptr(), 1, _stream())
+        return dx, dw, None
+
+
+def rmsnorm(x, w, eps=1e-6):
+    return RMSNormFn.apply(x, w, eps)
+
+
+class AdaRMSFn(torch.autograd.Function):
+    """adaRMSNorm given the precomputed modulation `mod` = dense(cond) [B, 3D] f32. Returns (y, gate)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, rows_per_batch: int, eps: float):
+        _chk(x, BF16, "adarms.x")
+        _chk(mod, F32, "adarms.mod")
+        rows, D = x.shape
+        Bn = rows // rows_per_batch
+        y = torch.empty_like(x)
+        gate = torch.empty((Bn, D), dtype=BF16, device=x.device)
+        rstd = torch.empty((rows,), dtype=F32, device=x.device)
+        _lib.call("kai0_adarms_fwd", x.data_ptr(), mod.data_ptr(), y.data_ptr(), gate.data_ptr(), rstd.data_ptr(), rows,
+                  rows_per_batch, D, eps, _stream())  # fmt: skip
+        ctx.save_for_backward(x, mod, rstd)
+        ctx.rpb = rows_per_batch
+        return y, gate
+
+    @staticmethod
+    def backward(ctx, dy, dgate):
+        x, mod, rstd = ctx.saved_tensors
+        rows, D = x.shape
+        dy = dy.contiguous()
+        dgate = dgate.contiguous() if dgate is not None else None
+        dx = torch.empty_like(x)
+        dmod = torch.empty_like(mod)
+        _lib.call("kai0_adarms_bwd", dy.data_ptr(), _p(dgate), x.data_ptr(), mod.data_ptr(), rstd.data_ptr(),
+                  dx.data_ptr(), dmod.data_ptr(), rows, ctx.rpb, D, _stream())  # fmt: skip
+        return dx, dmod, None, None
+
+
+def adarms(x, mod, rows_per_batch, eps=1e-6):
+    return AdaRMSFn.apply(x, mod, rows_per_batch, eps)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps: float):
+        _chk(x, BF16, "layernorm.x")
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), dtype=F32, device=x.device)
+        rstd = torch.empty((rows,), dtype=F32, device=x.device)
+        _lib.call("kai0_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), rows, D, eps, _stream())  # fmt: skip
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, D = x.shape
+        dx = torch.empty_like(x)
+        nb = NORM_PARTIAL_BLOCKS
+        part = torch.empty((nb * 4, 2 * D), dtype=F32, device=x.device)
+        _lib.call("kai0_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  dx.data_ptr(), part.data_ptr(), nb, rows, D, _stream())  # fmt: skip
+        dwb = torch.empty((2 * D,), dtype=w.dtype, device=x.device)
+        _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, 2 * D, dwb.data_ptr(), int(w.dtype == F32), _stream())
+        return dx, dwb[:D], dwb[D:], None
+
+
+def layernorm(x, w, b, eps=1e-6):
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, u):
+        _chk(g, BF16, "geglu.g")
+        _chk(u, BF16, "geglu.u")
+        h = torch.empty_like(g)
+        _lib.call("kai0_geglu_fwd", g.data_ptr(), u.data_ptr(), h.data_ptr(), g.numel(), _stream())
+        ctx.save_for_backward(g, u)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        g, u = ctx.saved_tensors
+        dh = dh.contiguous()
+        dg = torch.empty_like(g)
+        du = torch.empty_like(u)
+        _lib.call("kai0_geglu_bwd", dh.data_ptr(), g.data_ptr(), u.data_ptr(), dg.data_ptr(), du.data_ptr(), g.numel(),
+                  _stream())  # fmt: skip
+        return dg, du
+
+
+def geglu(g, u):
+    return GegluFn.apply(g, u)
+
+
+class GatedResidualFn(torch.autograd.Function):
+    """out = x + y * gate[b]  (modeling_gemma.py:209-227), gate [B, D] broadcast over the rows of batch b."""
+
+    @staticmethod
+    def forward(ctx, x, y, gate, rows_per_batch: int):
+        rows, D = x.shape
+        out = torch.empty_like(x)
+        _lib.call("kai0_gated_fwd", x.data_ptr(), y.data_ptr(), gate.data_ptr(), out.data_ptr(), rows, rows_per_batch, D,
+                  _stream())  # fmt: skip
+        ctx.save_for_backward(y, gate)
+        ctx.rpb = rows_per_batch
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gate = ctx.saved_tensors
+        dout = dout.contiguous()
+        rows, D = y.shape
+        dy = torch.empty_like(y)
+        dgate = torch.empty_like(gate)
+        _lib.call("kai0_gated_bwd", dout.data_ptr(), y.data_ptr(), gate.data_ptr(), dy.data_ptr(), dgate.data_ptr(), rows,
+                  ctx.rpb, D, _stream())  # fmt: skip
+        return dout, dy, dgate, None
+
+
+def gated_residual(x, y, gate, rows_per_batch):
+    return GatedResidualFn.apply(x, y, gate, rows_per_batch)
+
+
+class SiluF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, F32, "silu.x")
+        y = torch.empty_like(x)
+        _lib.call("kai0_silu_fwd_f32", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.call("kai0_silu_bwd_f32", dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream())
+        return dx
+
+
+def silu_f32(x):
+    return SiluF32Fn.apply(x)
+
+
+class CastFn(torch.autograd.Function):
+    """dtype cast f32<->bf16 whose backward casts the gradient back (autograd `.to()` semantics)."""
+
+    @staticmethod
+    def forward(ctx, x, to_bf16: bool):
+        ctx.to_bf16 = to_bf16
+        return cast(x, BF16 if to_bf16 else F32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return cast(dy.contiguous(), F32 if ctx.to_bf16 else BF16), None
+
+
+def cast(x: torch.Tensor, dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if dtype == BF16:
+        _chk(x, F32, "cast.x")
+        _lib.call("kai0_cast_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    else:
+        _chk(x, BF16, "cast.x")
+        _lib.call("kai0_cast_bf16_to_f32", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
+def cast_ag(x, dtype):
+    if x.dtype == dtype:
+        return x
+    return CastFn.apply(x, dtype == BF16)
+
+
+class EmbedFn(torch.autograd.Function):
+    """embed_tokens(tokens) * sqrt(D)  (gemma_pytorch.py:88-89; pi0_pytorch.py:213-216) -> [B*T, D] bf16."""
+
+    @staticmethod
+    def forward(ctx, table, tokens, scale: float):
+        _chk(table, BF16, "embed.table")
+        if tokens.dtype != torch.int64:
+            raise TypeError("embed.tokens must be int64")
+        Bn, T = tokens.shape
+        D = table.shape[1]
+        out = torch.empty((Bn * T, D), dtype=BF16, device=table.device)
+        _lib.call("kai0_embed_gather", table.data_ptr(), tokens.data_ptr(), out.data_ptr(), Bn, T, D, scale, T * D, 0, D,
+                  _stream())  # fmt: skip
+        ctx.save_for_backward(tokens)
+        ctx.shape = table.shape
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        Bn, T = tokens.shape
+        V, D = ctx.shape
+        dtable = torch.zeros((V, D), dtype=BF16, device=dout.device)
+        _lib.call("kai0_embed_grad", dout.data_ptr(), tokens.data_ptr(), dtable.data_ptr(), Bn, T, D, ctx.scale, T * D, 0,
+                  D, _stream())  # fmt: skip
+        return dtable, None, None
+
+
+def embed(table, tokens, scale):
+    return EmbedFn.apply(table, tokens.contiguous(), scale)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """SigLIP patch embedding: Conv2d(3->D, k=P, s=P) as im2col + exact-f32 GEMM, + position embedding, cast to
+    bf16 (modeling_siglip.py:220-226,271-281,777-778).  img f32 [N,3,HW,HW] -> bf16 [N*G*G, D]."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, pos, patch: int):
+        _chk(img, F32, "patch_embed.img")
+        _chk(w, F32, "patch_embed.weight")
+        n, Cc, HW, _ = img.shape
+        D = w.shape[0]
+        G = HW // patch
+        Kd = Cc * patch * patch
+        rows = n * G * G
+        cols = torch.empty((rows, Kd), dtype=F32, device=img.device)
+        _lib.call("kai0_patch_im2col", img.data_ptr(), cols.data_ptr(), n, Cc, HW, patch, _stream())
+        pe = torch.empty((rows, D), dtype=F32, device=img.device)
+        w2 = w.view(D, Kd)
+        gemm_f32(cols, Kd, 1, w2, 1, Kd, pe, rows, D, Kd, bias=b)
+        out = torch.empty((rows, D), dtype=BF16, device=img.device)
+        _lib.call("kai0_add_pos_cast", pe.data_ptr(), pos.data_ptr(), out.data_ptr(), rows, G * G, D, _stream())
+        ctx.save_for_backward(cols)
+        ctx.dims = (n, G, D, Kd, tuple(w.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (cols,) = ctx.saved_tensors
+        n, G, D, Kd, wshape = ctx.dims
+        rows = n * G * G
+        d32 = cast(dout.contiguous(), F32)
+        dw = torch.empty((D, Kd), dtype=F32, device=dout.device)
+        gemm_f32(d32, 1, D, cols, Kd, 1, dw, D, Kd, rows)  # dw[d,k] = sum_r d32[r,d] cols[r,k]
+        db = torch.empty((D,), dtype=F32, device=dout.device)
+        ones = torch.ones((1, rows), dtype=F32, device=dout.device)
+        gemm_f32(ones, rows, 1, d32, D, 1, db.view(1, D), 1, D, rows)
+        # dpos[p,d] = sum_n d32[n*G*G + p, d]
+        GG = G * G
+        dpos = torch.empty((GG, D), dtype=F32, device=dout.device)
+        if n == 1:
+            dpos.copy_(d32)
+        else:
+            ones_n = torch.ones((1, n), dtype=F32, device=dout.device)
+            # view d32 as [n][GG*D]: dpos_flat[j] = sum_n d32[n, j]
+            gemm_f32(ones_n, n, 1, d32.view(n, GG * D), GG * D, 1, dpos.view(1, GG * D), 1, GG * D, n)
+        return None, dw.view(wshape), db, dpos, None
+
+
+def patch_embed(img, w, b, pos, patch):
+    return PatchEmbedFn.apply(img, w, b, pos, patch)
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _copy_rows(src, dst, Bn, rows, D, sbs, sr0, sld, dbs, dr0, dld):
+    _lib.call("kai0_copy_rows_bf16", src.data_ptr(), dst.data_ptr(), Bn, rows, D, sbs, sr0, sld, dbs, dr0, dld, _stream())
+
+
+def rope_(x, pos, inv_freq, Bn, S, s_ld, row0, H, HD, inverse=False):
+    _lib.call("kai0_rope_inplace", x.data_ptr(), pos.data_ptr(), inv_freq.data_ptr(), Bn, S, s_ld, row0, H, HD,
+              int(inverse), _stream())  # fmt: skip
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H, HD, scale):
+    """Prefix-LM masked multi-query attention over padded buffers (modeling_gemma.py:230-253).
+
+    q_all [B, S_ld, H*HD] (query rows q0..q0+Sq used), k_all/v_all [B, S_ld, HD] (rows >= Sk are zero).
+    The H query heads of a position are folded into the GEMM M dimension: Q viewed as [Sq*H, HD] per batch.
+    Returns (att [B, S_ld, H*HD] with rows q0..q0+Sq written, probs [B, Sq*H, S_ld])."""
+    dev = q_all.device
+    M = Sq * H
+    scores = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
+    gemm(q_all, k_all, scores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
+         sB=(S_ld * HD, 0), sC=(M * S_ld, 0), scale=scale, a_off_elems=q0 * H * HD)  # fmt: skip
+    probs = torch.empty_like(scores)
+    _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), probs.data_ptr(), _p(qcode), _p(kcode), Bn, Sq, H, Sk, S_ld,
+              M * S_ld, q0, qcode.stride(0) if qcode is not None else 0, kcode.stride(0) if kcode is not None else 0,
+              _stream())  # fmt: skip
+    att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+    gemm(probs, v_all, att, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
+         sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD)  # fmt: skip
+    return att, probs
+
+
+class JointAttentionFn(torch.autograd.Function):
+    """The shared attention of one joint layer (gemma_pytorch.py:165-219): concat the per-expert q/k/v over the
+    sequence, RoPE, prefix-LM masked MQA attention, split back.
+
+    Inputs are flat [B*S_i, ...] bf16 tensors per segment i (prefix, suffix); outputs are the flat attention
+    outputs per segment ([B*S_i, H*HD])."""
+
+    @staticmethod
+    def forward(ctx, pos, qcode, kcode, inv_freq, H: int, HD: int, seg_lens: tuple, *qkv):
+        nseg = len(seg_lens)
+        qs, ks, vs = qkv[0::3], qkv[1::3], qkv[2::3]
+        dev = qs[0].device
+        S = sum(seg_lens)
+        Bn = qs[0].shape[0] // seg_lens[0]
+        S_ld = round_up(S, 8)
+        q_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        k_all = torch.zeros((Bn, S_ld, HD), dtype=BF16, device=dev)
+        v_all = torch.zeros((Bn, S_ld, HD), dtype=BF16, device=dev)
+        r0 = 0
+        for i in range(nseg):
+            Li = seg_lens[i]
+            _copy_rows(qs[i], q_all, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
+            _copy_rows(ks[i], k_all, Bn, Li, HD, Li * HD, 0, HD, S_ld * HD, r0, HD)
+            _copy_rows(vs[i], v_all, Bn, Li, HD, Li * HD, 0, HD, S_ld * HD, r0, HD)
+            r0 += Li
+        rope_(q_all, pos, inv_freq, Bn, S, S_ld, 0, H, HD)
+        rope_(k_all, pos, inv_freq, Bn, S, S_ld, 0, 1, HD)
+        scale = HD**-0.5
+        att, probs = mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, S, 0, S, S_ld, H, HD, scale)
+        outs = []
+        r0 = 0
+        for i in range(nseg):
+            Li = seg_lens[i]
+            o = torch.empty((Bn * Li, H * HD), dtype=BF16, device=dev)
+            _copy_rows(att, o, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * H * HD, 0, H * HD)
+            outs.append(o)
+            r0 += Li
+        ctx.save_for_backward(q_all, k_all, v_all, probs, pos, inv_freq)
+        ctx.cfg = (Bn, S, S_ld, H, HD, seg_lens, scale)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        q_all, k_all, v_all, probs, pos, inv_freq = ctx.saved_tensors
+        Bn, S, S_ld, H, HD, seg_lens, scale = ctx.cfg
+        dev = q_all.device
+        M = S * H
+        datt = torch.zeros((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        r0 = 0
+        for i, Li in enumerate(seg_lens):
+            _copy_rows(douts[i].contiguous(), datt, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
+            r0 += Li
+        # dV[b] [S_ld, HD] = P[b]^T [S_ld, M] @ dO[b] [M, HD]
+        dv_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
+        gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
+             sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
+        # dP[b] [M, S_ld] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K])
+        dprobs = torch.empty_like(probs)
+        gemm(datt, v_all, dprobs, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
+             sB=(S_ld * HD, 0), sC=(M * S_ld, 0))  # fmt: skip
+        dscores = dprobs  # in place
+        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), dscores.data_ptr(), Bn * M, S, S_ld, scale,
+                  _stream())  # fmt: skip
+        # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
+        dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        gemm(dscores, k_all, dq_all, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
+             sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0))  # fmt: skip
+        # dK[b] [S_ld, HD] = dS[b]^T [S_ld, M] @ Q[b] [M, HD]
+        dk_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
+        gemm(dscores, q_all, dk_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
+             sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
+        rope_(dq_all, pos, inv_freq, Bn, S, S_ld, 0, H, HD, inverse=True)
+        rope_(dk_all, pos, inv_freq, Bn, S, S_ld, 0, 1, HD, inverse=True)
+        grads = []
+        r0 = 0
+        for Li in seg_lens:
+            dq = torch.empty((Bn * Li, H * HD), dtype=BF16, device=dev)
+            dk = torch.empty((Bn * Li, HD), dtype=BF16, device=dev)
+            dv = torch.empty((Bn * Li, HD), dtype=BF16, device=dev)
+            _copy_rows(dq_all, dq, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * H * HD, 0, H * HD)
+            _copy_rows(dk_all, dk, Bn, Li, HD, S_ld * HD, r0, HD, Li * HD, 0, HD)
+            _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * HD, 0, HD)
+            grads += [dq, dk, dv]
+            r0 += Li
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def joint_attention(pos, qcode, kcode, inv_freq, H, HD, seg_lens, qkv):
+    return JointAttentionFn.apply(pos, qcode, kcode, inv_freq, H, HD, tuple(seg_lens), *qkv)
+
+
+class SiglipAttentionFn(torch.autograd.Function):
+    """Unmasked multi-head attention of SigLIP (modeling_siglip.py:325-345): q,k,v flat [N*S, NH*HD] bf16."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, n_img: int, S: int, NH: int, HD: int):
+        dev = q.device
+        E = NH * HD
+        S_ld = round_up(S, 8)
+        scale = HD**-0.5
+        scores = torch.empty((n_img * NH, S, S_ld), dtype=BF16, device=dev)
+        gemm(q, k, scores, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=n_img * NH, batch_inner=NH,
+             sA=(S * E, HD), sB=(S * E, HD), sC=(NH * S * S_ld, S * S_ld), scale=scale)  # fmt: skip
+        probs = torch.empty_like(scores)
+        if S_ld != S:
+            probs.zero_()
+        _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), probs.data_ptr(), None, None, n_img * NH, S, 1, S, S_ld,
+                  S * S_ld, 0, 0, 0, _stream())  # fmt: skip
+        out = torch.empty((n_img * S, E), dtype=BF16, device=dev)
+        gemm(probs, v, out, M=S, N=HD, K=S, a_kc=True, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=n_img * NH,
+             batch_inner=NH, sA=(NH * S * S_ld, S * S_ld), sB=(S * E, HD), sC=(S * E, HD))  # fmt: skip
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.cfg = (n_img, S, S_ld, NH, HD, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, probs = ctx.saved_tensors
+        n_img, S, S_ld, NH, HD, scale = ctx.cfg
+        dev = q.device
+        E = NH * HD
+        dout = dout.contiguous()
+        nb = n_img * NH
+        sP = (NH * S * S_ld, S * S_ld)
+        sE = (S * E, HD)
+        dv = torch.empty_like(v)
+        gemm(probs, dout, dv, M=S, N=HD, K=S, a_kc=False, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
+             sA=sP, sB=sE, sC=sE)  # fmt: skip
+        dprobs = torch.empty_like(probs)
+        gemm(dout, v, dprobs, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=nb, batch_inner=NH, sA=sE, sB=sE, sC=sP)
+        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), dprobs.data_ptr(), nb * S, S, S_ld, scale,
+                  _stream())  # fmt: skip
+        dq = torch.empty_like(q)
+        gemm(dprobs, k, dq, M=S, N=HD, K=S, a_kc=True, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
+             sA=sP, sB=sE, sC=sE)  # fmt: skip
+        dk = torch.empty_like(k)
+        gemm(dprobs, q, dk, M=S, N=HD, K=S, a_kc=False, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
+             sA=sP, sB=sE, sC=sE)  # fmt: skip
+        return dq, dk, dv, None, None, None, None
+
+
+def siglip_attention(q, k, v, n_img, S, NH, HD):
+    return SiglipAttentionFn.apply(q, k, v, n_img, S, NH, HD)
+
+
+# ---------------------------------------------------------------------------------------- flow matching
+def flow_mix(noise, actions, time):
+    """x_t = t*noise + (1-t)*actions, u_t = noise - actions (pi0_pytorch.py:326-328)."""
+    Bn = actions.shape[0]
+    HA = actions.numel() // Bn
+    x_t = torch.empty_like(actions)
+    u_t = torch.empty_like(actions)
+    _lib.call("kai0_flow_mix", noise.data_ptr(), actions.data_ptr(), time.data_ptr(), x_t.data_ptr(), u_t.data_ptr(), Bn,
+              HA, _stream())  # fmt: skip
+    return x_t, u_t
+
+
+class MseFn(torch.autograd.Function):
+    """F.mse_loss(u, v, reduction="none") with gradient only into v (pi0_pytorch.py:373)."""
+
+    @staticmethod
+    def forward(ctx, u, v):
+        _chk(u, F32, "mse.u")
+        _chk(v, F32, "mse.v")
+        loss = torch.empty_like(v)
+        _lib.call("kai0_mse_fwd", u.data_ptr(), v.data_ptr(), loss.data_ptr(), v.numel(), _stream())
+        ctx.save_for_backward(u, v)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        u, v = ctx.saved_tensors
+        dl = dl.contiguous()
+        dv = torch.empty_like(v)
+        _lib.call("kai0_mse_bwd", u.data_ptr(), v.data_ptr(), dl.data_ptr(), dv.data_ptr(), v.numel(), _stream())
+        return None, dv
+
+
+def mse_loss(u, v):
+    return MseFn.apply(u, v)
+
+
+def euler_step_(x, v, dt: float):
+    _lib.call("kai0_euler_step", x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream())
+    return x
+
+
+def sqrt_scale(dim: int) -> float:
+    """`math.sqrt(dim)` as the f32 scalar torch multiplies a bf16 tensor by."""
+    return float(torch.tensor(math.sqrt(dim), dtype=torch.float32))

@@ -1,0 +1,465 @@
+"""Parity of every HIP kernel against a plain torch fp32 reference of the same op (run on the GPU box).
+Calls go through the C-ABI (kai0_amd.ops -> ctypes -> libkai0hip.so)."""
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from kai0_amd import ops as _ops
+
+    return _ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dtype=BF16, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def assert_close_bf16(out, ref, tol=6e-3, what=""):
+    """`ref` is an fp32 result; `out` is bf16: one bf16 rounding of the exact value is <= 2^-8 relative."""
+    out, ref = out.float(), ref.float()
+    err = (out - ref).abs()
+    bound = tol * ref.abs() + tol * ref.abs().mean() + 1e-6
+    bad = (err > bound).float().mean().item()
+    assert bad < 1e-4, f"{what}: {bad:.2e} of elements out of tolerance; rel-L2 {rel_err(out, ref):.3e}, max abs {err.max().item():.3e}"
+    assert rel_err(out, ref) < 4e-3, f"{what}: rel-L2 {rel_err(out, ref):.3e}"
+
+
+# --------------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [
+    (128, 128, 64),
+    (256, 384, 512),
+    (200, 136, 72),      # ragged M, N; K tail (72 = 64 + 8)
+    (968, 2048, 2048),   # one pi0.5 prefix sample through q_proj
+    (50, 1024, 1024),    # one action-expert chunk
+    (1018 * 2, 256, 2048),
+    (264, 4304, 1152),   # SigLIP fc1 (N = 4304 = 33.6 tiles)
+    (264, 1152, 4304),   # SigLIP fc2 (K tail: 4304 = 67*64 + 16)
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt(ops, M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    out = ops.linear_fwd(x, w)
+    ref = x.float() @ w.float().t()
+    assert_close_bf16(out, ref, what=f"NT {M}x{N}x{K}")
+
+
+def test_gemm_nt_is_not_transposed(ops):
+    """A = I check with an asymmetric B (guide rule: symmetric inputs hide a row/col swap)."""
+    n = 128
+    eye = torch.eye(n, dtype=BF16, device=dev())
+    w = (torch.arange(n * n, device=dev()).reshape(n, n) % 251).to(BF16) * 0.01
+    out = ops.linear_fwd(eye, w)  # I @ w^T = w^T
+    assert torch.equal(out, w.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 512, 384), (200, 136, 72), (968, 2048, 2048), (96, 72, 256)])
+def test_gemm_nn(ops, M, N, K):
+    """dgrad shape: C[M,N] = A[M,K] @ B[K,N], B stored [K][N] (contraction-strided -> ds_read_b64_tr_b16)."""
+    a, b = rnd(M, K, seed=3), rnd(K, N, seed=4, scale=0.05)
+    out = torch.empty((M, N), dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M=M, N=N, K=K, a_kc=True, b_kc=False, lda=K, ldb=N, ldc=N)
+    assert_close_bf16(out, a.float() @ b.float(), what=f"NN {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 500), (136, 72, 1000), (2048, 256, 3872), (72, 256, 264)])
+def test_gemm_tn(ops, M, N, K):
+    """wgrad shape: C[M,N] = A[K,M]^T @ B[K,N], both stored contraction-major."""
+    a, b = rnd(K, M, seed=5), rnd(K, N, seed=6, scale=0.05)
+    out = torch.empty((M, N), dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M=M, N=N, K=K, a_kc=False, b_kc=False, lda=M, ldb=N, ldc=N)
+    assert_close_bf16(out, a.float().t() @ b.float(), what=f"TN {M}x{N}x{K}")
+
+
+def test_gemm_tn_a_only(ops):
+    """C = A[K,M]^T @ B[N,K]^T (A contraction-strided, B K-contiguous)."""
+    M, N, K = 136, 200, 328
+    a, b = rnd(K, M, seed=7), rnd(N, K, seed=8, scale=0.05)
+    out = torch.empty((M, N), dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M=M, N=N, K=K, a_kc=False, b_kc=True, lda=M, ldb=K, ldc=N)
+    assert_close_bf16(out, a.float().t() @ b.float().t(), what="TN(a only)")
+
+
+def test_gemm_epilogue_bias_gelu_residual(ops):
+    M, N, K = 264, 520, 328
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.08)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out, pre = ops.linear_fwd(x, w, bias=bias, residual=res, act=1, want_pre=True)
+    y = (x.float() @ w.float().t() + bias.float()).to(BF16)
+    assert_close_bf16(pre, y.float(), what="pre-activation")
+    ref = (torch.nn.functional.gelu(pre.float(), approximate="tanh").to(BF16).float() + res.float())
+    assert_close_bf16(out, ref, what="bias+gelu+residual")
+    # f32 bias variant
+    out2 = ops.linear_fwd(x, w, bias=bias.float())
+    assert_close_bf16(out2, x.float() @ w.float().t() + bias.float(), what="f32 bias")
+
+
+def test_gemm_epilogue_gate_scale(ops):
+    B, rpb, N, K = 3, 50, 136, 264
+    M = B * rpb
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.08)
+    gate, res = rnd(B, N, seed=5), rnd(M, N, seed=6)
+    out = ops.linear_fwd(x, w, residual=res, gate=gate, gate_rpb=rpb)
+    y = (x.float() @ w.float().t()).to(BF16).float()
+    ref = (y * gate.float().repeat_interleave(rpb, 0)).to(BF16).float() + res.float()
+    assert_close_bf16(out, ref, what="gate+residual")
+    out = torch.empty((M, N), dtype=BF16, device=dev())
+    ops.gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, scale=0.0625)
+    assert_close_bf16(out, y * 0.0625, what="scale")
+
+
+def test_gemm_row_remaps_and_batch(ops):
+    """c_map writes flat rows into a padded [B, S_ld, N] buffer; a_map reads them back; batched two-level strides."""
+    B, rows, S_ld, row0, N, K = 3, 50, 64, 8, 136, 72
+    x, w = rnd(B * rows, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    buf = torch.zeros((B, S_ld, N), dtype=BF16, device=dev())
+    ops.gemm(x, w, buf, M=B * rows, N=N, K=K, lda=K, ldb=K, ldc=N, c_map=(rows, S_ld, row0))
+    ref = (x.float() @ w.float().t()).view(B, rows, N)
+    assert_close_bf16(buf[:, row0 : row0 + rows], ref, what="c_map")
+    assert float(buf[:, :row0].abs().max()) == 0.0 and float(buf[:, row0 + rows :].abs().max()) == 0.0
+    w2 = rnd(K, N, seed=3, scale=0.1)  # [N2=K, K2=N]
+    out = torch.empty((B * rows, K), dtype=BF16, device=dev())
+    ops.gemm(buf, w2, out, M=B * rows, N=K, K=N, lda=N, ldb=N, ldc=K, a_map=(rows, S_ld, row0))
+    ref2 = buf[:, row0 : row0 + rows].reshape(B * rows, N).float() @ w2.float().t()
+    assert_close_bf16(out, ref2, what="a_map")
+    # TN with a remapped contraction index
+    g = rnd(B * rows, K, seed=4)
+    dw = torch.empty((N, K), dtype=BF16, device=dev())
+    ops.gemm(buf, g, dw, M=N, N=K, K=B * rows, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, a_map=(rows, S_ld, row0))
+    ref3 = buf[:, row0 : row0 + rows].reshape(B * rows, N).float().t() @ g.float()
+    assert_close_bf16(dw, ref3, what="a_map on contraction rows")
+    # batched heads: q [n, S, NH*HD] x k -> scores [n*NH, S, S]
+    n, S, NH, HD = 2, 16, 4, 72
+    E = NH * HD
+    q, k = rnd(n * S, E, seed=5), rnd(n * S, E, seed=6)
+    sc = torch.empty((n * NH, S, S), dtype=BF16, device=dev())
+    ops.gemm(q, k, sc, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S, batch=n * NH, batch_inner=NH, sA=(S * E, HD), sB=(S * E, HD),
+             sC=(NH * S * S, S * S))
+    qh = q.view(n, S, NH, HD).permute(0, 2, 1, 3).float()
+    kh = k.view(n, S, NH, HD).permute(0, 2, 1, 3).float()
+    assert_close_bf16(sc.view(n, NH, S, S), qh @ kh.transpose(-1, -2), what="two-level batch")
+
+
+def test_gemm_n_not_multiple_of_8(ops):
+    M, N, K, ld = 64, 20, 72, 24
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    out = torch.full((M, ld), 7.0, dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=ld)
+    assert_close_bf16(out[:, :N], a.float() @ b.float().t(), what="N=20")
+    assert float(out[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from kai0_amd._lib import Kai0HipError
+
+    a, b = rnd(64, 72), rnd(64, 72)
+    out = torch.empty((64, 64), dtype=BF16, device=dev())
+    with pytest.raises(Kai0HipError):
+        ops.gemm(a, b, out, M=64, N=64, K=72, lda=70, ldb=72, ldc=64)  # lda not a multiple of 8
+    with pytest.raises(Kai0HipError):
+        ops.linear_fwd(a.cpu(), b.cpu())  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 3072, 1024), (1600, 32, 1024), (100, 1152, 588), (5, 7, 3)])
+def test_gemm_f32(ops, M, N, K):
+    x, w, b = rnd(M, K, dtype=F32, seed=1), rnd(N, K, dtype=F32, seed=2, scale=0.05), rnd(N, dtype=F32, seed=3)
+    out = torch.empty((M, N), dtype=F32, device=dev())
+    ops.gemm_f32(x, K, 1, w, 1, K, out, M, N, K, bias=b)
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel_err(out, ref) < 2e-6
+    # strided: out2 = x^T-style wgrad  dw[n,k] = sum_m dy[m,n] x[m,k]
+    dy = rnd(M, N, dtype=F32, seed=4)
+    dw = torch.empty((N, K), dtype=F32, device=dev())
+    ops.gemm_f32(dy, 1, N, x, K, 1, dw, N, K, M)
+    assert rel_err(dw, dy.double().t() @ x.double()) < 2e-6
+
+
+# --------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,D", [(7, 64), (968, 2048), (50, 1024), (300, 1152)])
+def test_rmsnorm_fwd_bwd(ops, rows, D):
+    x = rnd(rows, D, seed=1).requires_grad_(True)
+    w = rnd(D, dtype=F32, seed=2, scale=0.3).requires_grad_(True)
+    dy = rnd(rows, D, seed=3)
+    y = ops.rmsnorm(x, w, 1e-6)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    var = xr.pow(2).mean(-1, keepdim=True)
+    yr = xr * torch.rsqrt(var + 1e-6) * (1.0 + wr)
+    yr.backward(dy.float())
+    assert_close_bf16(y, yr, what="rmsnorm y")
+    assert_close_bf16(x.grad, xr.grad, what="rmsnorm dx", tol=1e-2)
+    assert rel_err(w.grad, wr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("B,rpb,D", [(3, 50, 1024), (2, 5, 64)])
+def test_adarms_fwd_bwd(ops, B, rpb, D):
+    rows = B * rpb
+    x = rnd(rows, D, seed=1).requires_grad_(True)
+    mod = rnd(B, 3 * D, dtype=F32, seed=2, scale=0.3).requires_grad_(True)
+    dy, dgate = rnd(rows, D, seed=3), rnd(B, D, seed=4)
+    y, gate = ops.adarms(x, mod, rpb, 1e-6)
+    torch.autograd.backward([y, gate], [dy, dgate])
+    xr = x.detach().float().requires_grad_(True)
+    mr = mod.detach().clone().requires_grad_(True)
+    scale, shift, gt = mr.view(B, 1, 3 * D).chunk(3, dim=-1)
+    x3 = xr.view(B, rpb, D)
+    var = x3.pow(2).mean(-1, keepdim=True)
+    yr = x3 * torch.rsqrt(var + 1e-6) * (1 + scale) + shift
+    torch.autograd.backward([yr, gt.squeeze(1)], [dy.float().view(B, rpb, D), dgate.float()])
+    assert_close_bf16(y, yr.reshape(rows, D), what="adarms y")
+    assert_close_bf16(gate, gt.squeeze(1), what="adarms gate")
+    assert_close_bf16(x.grad, xr.grad, what="adarms dx", tol=1e-2)
+    assert rel_err(mod.grad, mr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("rows,D", [(512, 1152), (9, 64)])
+def test_layernorm_fwd_bwd(ops, rows, D):
+    x = rnd(rows, D, seed=1).requires_grad_(True)
+    w = (1 + rnd(D, seed=2, scale=0.2).float()).to(BF16).requires_grad_(True)
+    b = rnd(D, seed=3, scale=0.2).requires_grad_(True)
+    dy = rnd(rows, D, seed=4)
+    y = ops.layernorm(x, w, b, 1e-6)
+    y.backward(dy)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-6)
+    yr.backward(dy.float())
+    assert_close_bf16(y, yr, what="layernorm y")
+    assert_close_bf16(x.grad, xr.grad, what="layernorm dx", tol=1e-2)
+    assert rel_err(w.grad, wr.grad) < 1e-2 and rel_err(b.grad, br.grad) < 1e-2
+
+
+def test_linear_autograd(ops):
+    M, N, K = 264, 328, 200
+    x = rnd(M, K, seed=1).requires_grad_(True)
+    w = rnd(N, K, seed=2, scale=0.08).requires_grad_(True)
+    bias = rnd(N, seed=3).requires_grad_(True)
+    res = rnd(M, N, seed=4).requires_grad_(True)
+    dy = rnd(M, N, seed=5)
+    out = ops.linear(x, w, bias, res, 1)
+    out.backward(dy)
+    xr, wr, br, rr = (t.detach().float().requires_grad_(True) for t in (x, w, bias, res))
+    ref = torch.nn.functional.gelu(xr @ wr.t() + br, approximate="tanh") + rr
+    ref.backward(dy.float())
+    assert_close_bf16(out, ref, what="linear out", tol=1e-2)
+    assert_close_bf16(x.grad, xr.grad, what="linear dx", tol=1.5e-2)
+    assert_close_bf16(w.grad, wr.grad, what="linear dw", tol=1.5e-2)
+    assert rel_err(bias.grad, br.grad) < 1e-2
+    assert torch.equal(res.grad, dy)
+
+
+def test_linear_f32_autograd(ops):
+    M, N, K = 37, 96, 200
+    x = rnd(M, K, dtype=F32, seed=1).requires_grad_(True)
+    w = rnd(N, K, dtype=F32, seed=2, scale=0.1).requires_grad_(True)
+    b = rnd(N, dtype=F32, seed=3).requires_grad_(True)
+    dy = rnd(M, N, dtype=F32, seed=4)
+    ops.silu_f32(ops.linear_f32(x, w, b)).backward(dy)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.silu(xr @ wr.t() + br).backward(dy.double())
+    for a, r in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+        assert rel_err(a, r) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- elementwise
+def test_geglu_and_gated_residual(ops):
+    g = rnd(200, 136, seed=1).requires_grad_(True)
+    u = rnd(200, 136, seed=2).requires_grad_(True)
+    dh = rnd(200, 136, seed=3)
+    h = ops.geglu(g, u)
+    h.backward(dh)
+    gr, ur = (t.detach().float().requires_grad_(True) for t in (g, u))
+    hr = torch.nn.functional.gelu(gr, approximate="tanh") * ur
+    hr.backward(dh.float())
+    assert_close_bf16(h, hr, what="geglu", tol=1e-2)
+    assert_close_bf16(g.grad, gr.grad, what="geglu dg", tol=1.5e-2)
+    assert_close_bf16(u.grad, ur.grad, what="geglu du", tol=1e-2)
+    B, rpb, D = 3, 50, 136
+    x = rnd(B * rpb, D, seed=4).requires_grad_(True)
+    y = rnd(B * rpb, D, seed=5).requires_grad_(True)
+    gate = rnd(B, D, seed=6).requires_grad_(True)
+    do = rnd(B * rpb, D, seed=7)
+    o = ops.gated_residual(x, y, gate, rpb)
+    o.backward(do)
+    xr, yr, gtr = (t.detach().float().requires_grad_(True) for t in (x, y, gate))
+    orf = xr + yr * gtr.repeat_interleave(rpb, 0)
+    orf.backward(do.float())
+    assert_close_bf16(o, orf, what="gated", tol=1e-2)
+    assert torch.equal(x.grad, do)
+    assert_close_bf16(y.grad, yr.grad, what="gated dy", tol=1e-2)
+    assert_close_bf16(gate.grad, gtr.grad, what="gated dgate", tol=1e-2)
+
+
+def _rope_ref(x, pos, inv_freq, inverse=False):
+    """modeling_gemma.py:149-194 in bf16: x [B, S, H, HD], pos [B, S]."""
+    freqs = pos[:, :, None].float() * inv_freq[None, None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos().to(BF16)[:, :, None, :], emb.sin().to(BF16)[:, :, None, :]
+    if inverse:
+        sin = -sin
+    half = x.shape[-1] // 2
+    rot = torch.cat((-x[..., half:], x[..., :half]), dim=-1)
+    return (x * cos) + (rot * sin)
+
+
+@pytest.mark.parametrize("H,HD", [(8, 256), (1, 256), (8, 16)])
+def test_rope(ops, H, HD):
+    B, S, S_ld, row0 = 2, 50, 64, 8
+    x = rnd(B, S_ld, H * HD, seed=1)
+    pos = torch.randint(0, 1100, (B, S), device=dev(), dtype=torch.int32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, HD, 2, dtype=torch.int64).float() / HD)).to(dev())
+    ref = x.clone()
+    ref[:, row0 : row0 + S] = _rope_ref(x[:, row0 : row0 + S].reshape(B, S, H, HD), pos, inv).reshape(B, S, H * HD)
+    y = x.clone()
+    ops.rope_(y, pos, inv, B, S, S_ld, row0, H, HD)
+    # cos/sin of a large angle may differ by one bf16 ulp between libms: allow a handful of 1-ulp flips
+    mism = (y != ref).float().mean().item()
+    assert mism < 2e-2, f"rope mismatch fraction {mism}"
+    assert rel_err(y, ref) < 3e-3
+    assert torch.equal(y[:, :row0], x[:, :row0]) and torch.equal(y[:, row0 + S :], x[:, row0 + S :])
+
+
+def test_softmax_mask(ops):
+    B, Sq, H, Sk, ld = 2, 24, 8, 40, 48
+    M = Sq * H
+    scores = rnd(B, M, ld, seed=1, scale=3.0)
+    pad = torch.ones((B, Sk), dtype=torch.bool, device=dev())
+    pad[0, 10:14] = False
+    pad[1, 30:] = False
+    att = torch.zeros((B, Sk), dtype=torch.bool, device=dev())
+    att[:, 32] = True  # last 8 tokens form the "suffix"
+    from kai0_amd.model import build_mask_codes
+
+    qcode, kcode, _ = build_mask_codes(pad, att)
+    q0 = Sk - Sq
+    probs = torch.empty_like(scores)
+    from kai0_amd import _lib
+
+    _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), probs.data_ptr(), qcode.data_ptr(), kcode.data_ptr(), B, Sq, H,
+              Sk, ld, M * ld, q0, qcode.stride(0), kcode.stride(0), ops._stream())
+    cum = torch.cumsum(att.int(), 1)
+    m2d = (cum[:, None, :] <= cum[:, :, None]) & (pad[:, None, :] & pad[:, :, None])  # [B, Sk, Sk]
+    m2d = m2d[:, q0:, :]  # query rows
+    s = scores[:, :, :Sk].float().view(B, Sq, H, Sk)
+    s = s + torch.where(m2d[:, :, None, :], 0.0, -2.3819763e38)
+    ref = torch.softmax(s, dim=-1)
+    valid_q = pad[:, q0:]
+    got = probs[:, :, :Sk].float().view(B, Sq, H, Sk)
+    assert_close_bf16(got[valid_q], ref[valid_q], what="softmax", tol=1e-2)
+    assert float(probs[:, :, Sk:].abs().max()) == 0.0
+    assert float(got[~valid_q].abs().max()) == 0.0  # fully masked (padded) query rows are defined as zeros
+    # backward
+    dp = rnd(B, M, ld, seed=2)
+    ds = torch.empty_like(dp)
+    _lib.call("kai0_softmax_bwd", probs.data_ptr(), dp.data_ptr(), ds.data_ptr(), B * M, Sk, ld, 0.5, ops._stream())
+    p = probs.float()[:, :, :Sk]
+    d = dp.float()[:, :, :Sk]
+    refd = p * (d - (p * d).sum(-1, keepdim=True)) * 0.5
+    assert_close_bf16(ds[:, :, :Sk], refd, what="softmax bwd", tol=1.5e-2)
+
+
+def test_embed_and_grad(ops):
+    V, D, B, T = 300, 136, 3, 20
+    table = rnd(V, D, seed=1).requires_grad_(True)
+    tok = torch.randint(0, V, (B, T), device=dev())
+    tok[0, :5] = 7  # repeated ids
+    scale = ops.sqrt_scale(D)
+    out = ops.embed(table, tok, scale)
+    ref = (table.detach()[tok.view(-1)].float() * scale).to(BF16)
+    assert torch.equal(out, ref)
+    do = rnd(B * T, D, seed=2)
+    out.backward(do)
+    refg = torch.zeros(V, D, device=dev())
+    refg.index_add_(0, tok.view(-1), (do.float() * scale).to(BF16).float())
+    assert_close_bf16(table.grad, refg, what="embed grad")
+
+
+def test_patch_embed(ops):
+    n, HW, P, D = 3, 56, 14, 72
+    img = rnd(n, 3, HW, HW, dtype=F32, seed=1)
+    w = rnd(D, 3, P, P, dtype=F32, seed=2, scale=0.05).requires_grad_(True)
+    b = rnd(D, dtype=F32, seed=3).requires_grad_(True)
+    pos = rnd((HW // P) ** 2, D, dtype=F32, seed=4).requires_grad_(True)
+    out = ops.patch_embed(img, w, b, pos, P)
+    do = rnd(*out.shape, seed=5)
+    out.backward(do)
+    wr, br, pr = (t.detach().clone().requires_grad_(True) for t in (w, b, pos))
+    ref = torch.nn.functional.conv2d(img, wr, br, stride=P).flatten(2).transpose(1, 2) + pr[None]
+    ref.reshape(-1, D).backward(do.float())
+    assert_close_bf16(out, ref.reshape(-1, D), what="patch embed")
+    for a, r in ((w.grad, wr.grad), (b.grad, br.grad), (pos.grad, pr.grad)):
+        assert rel_err(a, r) < 1e-4
+
+
+def test_time_sincos_and_flow(ops):
+    from kai0_amd import _lib
+
+    B, dim = 5, 1024
+    t = torch.rand(B, device=dev()) * 0.999 + 0.001
+    out = torch.empty((B, dim), dtype=F32, device=dev())
+    _lib.call("kai0_time_sincos", t.data_ptr(), out.data_ptr(), B, dim, 4e-3, 4.0, ops._stream())
+    frac = torch.linspace(0.0, 1.0, dim // 2, dtype=torch.float64, device=dev())
+    period = 4e-3 * (4.0 / 4e-3) ** frac
+    x = (1.0 / period * 2 * math.pi)[None, :] * t.double()[:, None]
+    ref = torch.cat([torch.sin(x), torch.cos(x)], dim=1).float()
+    assert float((out - ref).abs().max()) < 1e-6
+    a, nz = rnd(B, 50, 32, dtype=F32, seed=1), rnd(B, 50, 32, dtype=F32, seed=2)
+    xt, ut = ops.flow_mix(nz, a, t)
+    assert torch.allclose(xt, t[:, None, None] * nz + (1 - t[:, None, None]) * a, atol=1e-6)
+    assert torch.equal(ut, nz - a)
+    v = rnd(B * 50, 32, dtype=F32, seed=3).requires_grad_(True)
+    loss = ops.mse_loss(ut.view(B * 50, 32), v)
+    loss.mean().backward()
+    vr = v.detach().clone().requires_grad_(True)
+    torch.nn.functional.mse_loss(ut.view(B * 50, 32), vr, reduction="none").mean().backward()
+    assert torch.allclose(v.grad, vr.grad, rtol=1e-5, atol=1e-8)
+    xx = xt.clone()
+    ops.euler_step_(xx, ut, -0.1)
+    assert torch.allclose(xx, xt - 0.1 * ut, atol=1e-6)
+
+
+def test_casts(ops):
+    x = rnd(1000, 37, dtype=F32, seed=1)
+    assert torch.equal(ops.cast(x, BF16), x.to(BF16))
+    assert torch.equal(ops.cast(x.to(BF16), F32), x.to(BF16).float())
+
+
+def test_adamw_and_clip(ops):
+    from kai0_amd.optim import FusedAdamW
+
+    torch.manual_seed(0)
+    params = [rnd(1000, 33, seed=1).requires_grad_(True), rnd(513, dtype=F32, seed=2).requires_grad_(True)]
+    ref = [p.detach().float().clone().requires_grad_(True) for p in params]
+    opt = FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0)
+    ropt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2)
+    for step in range(3):
+        for p, r in zip(params, ref):
+            g = rnd(*p.shape, dtype=F32, seed=10 + step) * 3
+            p.grad = g.to(p.dtype)
+            r.grad = g.to(p.dtype).float()
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        norm = opt.step()
+        assert abs(float(norm) - float(norm_ref)) / float(norm_ref) < 1e-4
+    for p, r, m in zip(params, ref, opt.master_params()):
+        assert rel_err(m, r) < 1e-5
+        assert torch.equal(p.detach(), m.to(p.dtype))
