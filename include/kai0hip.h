@@ -62,7 +62,7 @@ int kai0_device_info(int device, int* n_cu, int* lds_bytes, char* arch_name64);
  *   if gate:       v = bf16(v * gate[row / gate_rpb][col])          (_gated_residual, modeling_gemma.py:209-227)
  *   if residual:   v = bf16(v + residual[row][col])
  *   if accumulate: v = v + C_old  (f32 out: exact; bf16 out: rounded once)
- *   C = v (bf16, or f32 when out_f32)
+ *   C = v (bf16, or f32 when out_f32; with out_f32 none of the bf16 rounding steps above is applied)
  */
 typedef struct kai0_gemm_desc {
     const void* A;
@@ -147,9 +147,11 @@ int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_freq, int B,
 int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode, const int32_t* kcode,
                           int B, int Sq, int H, int Sk, int64_t ld, int64_t batch_stride, int q0,
                           int64_t qcode_ld, int64_t kcode_ld, kai0_stream_t stream);
-/* dscores = bf16( (probs * (dprobs - sum_j dprobs*probs)) * scale ) */
-int kai0_softmax_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int Sk, int64_t ld,
-                     float scale, kai0_stream_t stream);
+/* dscores = bf16( (probs * (dprobs - sum_j dprobs*probs)) * scale ).  dprobs is bf16 or (dprobs_f32) f32:
+ * with near-uniform attention dprobs - <dprobs,probs> cancels catastrophically, so the training path keeps
+ * dP = dO V^T in f32 (the reference's autograd rounds it to bf16; this is the more accurate of the two). */
+int kai0_softmax_bwd(const void* probs, const void* dprobs, int dprobs_f32, void* dscores, int64_t rows, int Sk,
+                     int64_t ld, float scale, kai0_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces.

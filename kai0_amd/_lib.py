@@ -55,7 +55,7 @@ _PROTOS: dict[str, list] = {
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
     "kai0_softmax_mask_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
-    "kai0_softmax_bwd": [c_p, c_p, c_p, c_i64, c_i, c_i64, c_f, c_p],
+    "kai0_softmax_bwd": [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_f, c_p],
     "kai0_geglu_fwd": [c_p, c_p, c_p, c_i64, c_p],
     "kai0_geglu_bwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
     "kai0_gelu_bwd": [c_p, c_p, c_p, c_i64, c_p],
@@ -102,6 +102,11 @@ def load() -> C.CDLL:
             f"{path} not found: the HIP extension is not built. Run `python -m kai0_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path."
         )
+    # The kernels must run on the SAME HIP runtime instance as PyTorch (its streams and device pointers are
+    # passed straight through the C ABI).  torch bundles its own libamdhip64; importing torch first makes the
+    # dynamic loader resolve this library's libamdhip64.so.N dependency to that already-loaded copy.
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(path))
     lib.kai0_last_error.restype = C.c_char_p
     lib.kai0_last_error.argtypes = []

@@ -11,13 +11,16 @@ SRC = ["runtime.hip", "gemm_bf16.hip", "gemm_f32.hip", "norm.hip", "elementwise.
 OUT = HERE / "lib" / "libkai0hip.so"
 
 
+# -ffp-contract=off: torch's eager ops never fuse a multiply into a following add, and hipcc's default
+# (-ffp-contract=fast) even contracts ACROSS an explicit bf16 round trip (it narrows fpext*fpext products to
+# bf16 ops and then forms a bf16 fma), which silently removes the bf16 rounding points this library emulates.
 def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     srcs = [HERE / "csrc" / s for s in SRC]
     deps = srcs + [HERE / "csrc" / "common.h", HERE.parent / "include" / "kai0hip.h"]
     if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return OUT
     OUT.parent.mkdir(parents=True, exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off",
            *map(str, srcs), "-o", str(OUT)]  # fmt: skip
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* sco
     }
 }
 
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ probs, const bf16_t* dprobs,
+template <bool DP_F32>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ probs, const void* dprobs,
                                                           bf16_t* dscores, int64_t rows, int Sk, int64_t ld,
                                                           float scale) {
     const int lane = threadIdx.x & 63;
@@ -148,7 +149,15 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
                 ld8(probs + row * ld + ci * 8, p[c]);
-                ld8(dprobs + row * ld + ci * 8, dp[c]);
+                if constexpr (DP_F32) {
+                    const float* dpp = reinterpret_cast<const float*>(dprobs) + row * ld + ci * 8;
+                    f32x4 a = *reinterpret_cast<const f32x4*>(dpp);
+                    f32x4 b = *reinterpret_cast<const f32x4*>(dpp + 4);
+                    dp[c][0] = a[0]; dp[c][1] = a[1]; dp[c][2] = a[2]; dp[c][3] = a[3];
+                    dp[c][4] = b[0]; dp[c][5] = b[1]; dp[c][6] = b[2]; dp[c][7] = b[3];
+                } else {
+                    ld8(reinterpret_cast<const bf16_t*>(dprobs) + row * ld + ci * 8, dp[c]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (ci * 8 + e >= Sk) { p[c][e] = 0.f; dp[c][e] = 0.f; }
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
             if (ci < nchunk) {
                 float o[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rbf(p[c][e] * (dp[c][e] - dot)) * scale;
+                for (int e = 0; e < 8; ++e) o[e] = (p[c][e] * (dp[c][e] - dot)) * scale;
                 st8(dscores + row * ld + ci * 8, o);
             }
         }
@@ -472,12 +481,16 @@ KAI0_API int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_
     return kai0_check_launch("kai0_softmax_mask_fwd");
 }
 
-KAI0_API int kai0_softmax_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int Sk, int64_t ld,
-                              float scale, kai0_stream_t stream) {
+KAI0_API int kai0_softmax_bwd(const void* probs, const void* dprobs, int dprobs_f32, void* dscores, int64_t rows, int Sk,
+                              int64_t ld, float scale, kai0_stream_t stream) {
     KAI0_REQUIRE(ld % 8 == 0 && ld <= 4096 && Sk <= ld, "kai0_softmax_bwd: ld=%lld unsupported", (long long)ld);
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream), (const bf16_t*)probs,
-                       (const bf16_t*)dprobs, (bf16_t*)dscores, rows, Sk, ld, scale);
+    if (dprobs_f32)
+        hipLaunchKernelGGL((softmax_bwd_kernel<true>), dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream),
+                           (const bf16_t*)probs, dprobs, (bf16_t*)dscores, rows, Sk, ld, scale);
+    else
+        hipLaunchKernelGGL((softmax_bwd_kernel<false>), dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream),
+                           (const bf16_t*)probs, dprobs, (bf16_t*)dscores, rows, Sk, ld, scale);
     return kai0_check_launch("kai0_softmax_bwd");
 }
 

@@ -273,6 +273,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
             for (int e = 0; e < 8; ++e) bias8[e] = bf2f(bv[e]);
         }
     }
+    // f32 output keeps the raw accumulator (no bf16 rounding points): used for gradients that must not be
+    // quantised before a cancelling reduction (softmax backward).
+    const bool rnd = !p.out_f32;
+    auto R = [rnd](float x) { return rnd ? rbf(x) : x; };
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int lr = it * 8 + (lane >> 3);
@@ -284,10 +288,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const int64_t orow = p.cmap(row);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bias8[e]);
+        for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bias8[e]);
         if (p.scale != 1.0f) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * p.scale);
+            for (int e = 0; e < 8; ++e) v[e] = R(v[e] * p.scale);
         }
         if (p.act == 1) {
             if (p.pre_out != nullptr) {
@@ -297,17 +301,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
                 *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rbf(gelu_tanh_f(v[e]));
+            for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
         }
         if (p.gate != nullptr) {
             bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * bf2f(gv[e]));
+            for (int e = 0; e < 8; ++e) v[e] = R(v[e] * bf2f(gv[e]));
         }
         if (p.residual != nullptr) {
             bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rv[e]));
+            for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bf2f(rv[e]));
         }
         if (p.out_f32) {
             float* cp = reinterpret_cast<float*>(p.C) + cz + orow * p.ldc + ccol;

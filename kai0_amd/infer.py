@@ -117,7 +117,8 @@ class InferenceEngine:
         self.pos_prefix = pos[:, :P].contiguous()
         self.pos_suffix = pos[:, P:].contiguous()
         lm = pe.paligemma.model.language_model
-        inv_freq = lm.inv_freq
+        self._inv_freq = lm.rope_inv_freq()
+        inv_freq = lm.rope_inv_freq()
         H, HD, S_ld = self.H, self.HD, self.S_ld
         xp = prefix.reshape(B * P, self.Dp)
         for l, layer in enumerate(lm.layers):
@@ -161,7 +162,7 @@ class InferenceEngine:
         B, P, Hs, De = self.B, self.P, self.Hs, self.De
         H, HD, S_ld = self.H, self.HD, self.S_ld
         ex = pe.gemma_expert.model
-        inv_freq = pe.paligemma.model.language_model.inv_freq
+        inv_freq = self._inv_freq
         a = ops.linear_f32(x_t.view(B * Hs, self.A), model.action_in_proj.weight, model.action_in_proj.bias)
         xs = ops.cast(a, BF16)
         rows = slice(step * B, (step + 1) * B)

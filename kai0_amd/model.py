@@ -128,6 +128,13 @@ class GemmaModel(nn.Module):
         inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.int64).to(dtype=torch.float) / hd))
         self.register_buffer("inv_freq", inv, persistent=False)
 
+    def rope_inv_freq(self) -> torch.Tensor:
+        """f32 table handed to the RoPE kernel.  NOTE (reference quirk, mirrored on purpose): the reference casts
+        the whole module with `self.to(dtype=torch.bfloat16)` (gemma_pytorch.py:64-65), which also rounds the
+        non-persistent `inv_freq` buffer to bf16; GemmaRotaryEmbedding.forward then upcasts it with `.float()`
+        (modeling_gemma.py:151).  So in bf16 mode the rotary frequencies ARE the bf16-rounded ones."""
+        return self.inv_freq.to(torch.float32).contiguous()
+
 
 class GemmaForCausalLM(nn.Module):
     def __init__(self, cfg, vocab: int, use_adarms: bool):
@@ -329,7 +336,7 @@ class PaliGemmaWithExpertModel(nn.Module):
         lm, ex = self.paligemma.model.language_model, self.gemma_expert.model
         cfg = self.vlm_cfg
         H, HD = cfg.num_heads, cfg.head_dim
-        inv_freq = lm.inv_freq
+        inv_freq = lm.rope_inv_freq()
 
         def layer_fn(xp, xs, lp, le):
             hp = ops.rmsnorm(xp, lp.input_layernorm.weight, lp.input_layernorm.eps)

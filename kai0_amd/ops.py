@@ -56,6 +56,11 @@ def gemm(
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
+    for t in (A, B, out):
+        if not t.is_cuda:
+            raise _lib.Kai0HipError("gemm: expected CUDA (HIP) tensors; the product path has no CPU fallback")
+    if A.dtype != BF16 or B.dtype != BF16:
+        raise TypeError(f"gemm: bf16 operands expected, got {A.dtype} / {B.dtype}")
     d = GemmDesc()
     d.A = A.data_ptr() + 2 * a_off_elems
     d.B = B.data_ptr() + 2 * b_off_elems
@@ -107,6 +112,9 @@ def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None,
 
 
 def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=False):
+    for t in (A, Bm, out):
+        if not t.is_cuda or t.dtype != F32:
+            raise _lib.Kai0HipError("gemm_f32: expected f32 CUDA (HIP) tensors; the product path has no CPU fallback")
     _lib.call("kai0_gemm_f32", A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, out.data_ptr(), out.stride(0), M, N, K,
               _p(bias), int(accumulate), _stream())  # fmt: skip
     return out
@@ -586,12 +594,14 @@ class JointAttentionFn(torch.autograd.Function):
         gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
              sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
         # dP[b] [M, S_ld] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K])
-        dprobs = torch.empty_like(probs)
+        # f32 on purpose: dP - <dP, P> cancels when attention is diffuse (see kai0_softmax_bwd in kai0hip.h)
+        dprobs = torch.empty(probs.shape, dtype=F32, device=dev)
         gemm(datt, v_all, dprobs, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
              sB=(S_ld * HD, 0), sC=(M * S_ld, 0))  # fmt: skip
-        dscores = dprobs  # in place
-        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), dscores.data_ptr(), Bn * M, S, S_ld, scale,
+        dscores = torch.empty_like(probs)
+        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), 1, dscores.data_ptr(), Bn * M, S, S_ld, scale,
                   _stream())  # fmt: skip
+        del dprobs
         # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
         dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
         gemm(dscores, k_all, dq_all, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
@@ -657,10 +667,12 @@ class SiglipAttentionFn(torch.autograd.Function):
         dv = torch.empty_like(v)
         gemm(probs, dout, dv, M=S, N=HD, K=S, a_kc=False, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
              sA=sP, sB=sE, sC=sE)  # fmt: skip
+        dprobs32 = torch.empty(probs.shape, dtype=F32, device=dev)
+        gemm(dout, v, dprobs32, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=nb, batch_inner=NH, sA=sE, sB=sE, sC=sP)
         dprobs = torch.empty_like(probs)
-        gemm(dout, v, dprobs, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=nb, batch_inner=NH, sA=sE, sB=sE, sC=sP)
-        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), dprobs.data_ptr(), nb * S, S, S_ld, scale,
+        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs32.data_ptr(), 1, dprobs.data_ptr(), nb * S, S, S_ld, scale,
                   _stream())  # fmt: skip
+        del dprobs32
         dq = torch.empty_like(q)
         gemm(dprobs, k, dq, M=S, N=HD, K=S, a_kc=True, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
              sA=sP, sB=sE, sC=sE)  # fmt: skip

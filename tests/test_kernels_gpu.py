@@ -370,11 +370,94 @@ def test_softmax_mask(ops):
     # backward
     dp = rnd(B, M, ld, seed=2)
     ds = torch.empty_like(dp)
-    _lib.call("kai0_softmax_bwd", probs.data_ptr(), dp.data_ptr(), ds.data_ptr(), B * M, Sk, ld, 0.5, ops._stream())
+    _lib.call("kai0_softmax_bwd", probs.data_ptr(), dp.data_ptr(), 0, ds.data_ptr(), B * M, Sk, ld, 0.5, ops._stream())
+    ds32 = torch.empty_like(dp)
+    _lib.call("kai0_softmax_bwd", probs.data_ptr(), dp.float().contiguous().data_ptr(), 1, ds32.data_ptr(), B * M, Sk, ld,
+              0.5, ops._stream())
+    assert torch.equal(ds, ds32)
     p = probs.float()[:, :, :Sk]
     d = dp.float()[:, :, :Sk]
     refd = p * (d - (p * d).sum(-1, keepdim=True)) * 0.5
     assert_close_bf16(ds[:, :, :Sk], refd, what="softmax bwd", tol=1.5e-2)
+
+
+def _mqa_ref(q, k, v, pos, inv, qcode, kcode, H, HD):
+    """fp32 reference of RoPE + prefix-LM masked MQA: q [B,S,H*HD], k/v [B,S,HD]."""
+    B, S, _ = q.shape
+    freqs = pos[:, :, None].float() * inv[None, None, :]
+    emb = torch.cat((freqs, freqs), -1)
+    cos, sin = emb.cos()[:, :, None, :], emb.sin()[:, :, None, :]
+
+    def rope(x):
+        half = x.shape[-1] // 2
+        return x * cos + torch.cat((-x[..., half:], x[..., :half]), -1) * sin
+
+    qh = rope(q.view(B, S, H, HD)).permute(0, 2, 1, 3)
+    kh = rope(k.view(B, S, 1, HD)).permute(0, 2, 1, 3)
+    vh = v.view(B, S, 1, HD).permute(0, 2, 1, 3)
+    sc = (qh @ kh.transpose(-1, -2)) * HD**-0.5
+    allowed = kcode[:, None, None, :] <= qcode[:, None, :, None]
+    sc = sc.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(sc, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, S, H * HD)
+
+
+@pytest.mark.parametrize("H,HD,P,Hs", [(8, 16, 20, 6), (8, 256, 40, 10)])
+def test_joint_attention_fwd_bwd(ops, H, HD, P, Hs):
+    from kai0_amd.model import build_mask_codes
+
+    B, S = 2, P + Hs
+    pad = torch.ones((B, S), dtype=torch.bool, device=dev())
+    pad[0, 3:6] = False
+    pad[1, P - 4 : P] = False
+    att = torch.zeros((B, S), dtype=torch.bool, device=dev())
+    att[:, P] = True
+    qcode, kcode, pos = build_mask_codes(pad, att)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, HD, 2, dtype=torch.int64).float() / HD))).to(dev())
+    segs = [(P, 1), (Hs, 2)]
+    flat = []
+    for L, sd in segs:
+        flat += [rnd(B * L, H * HD, seed=sd).requires_grad_(True), rnd(B * L, HD, seed=sd + 10).requires_grad_(True),
+                 rnd(B * L, HD, seed=sd + 20).requires_grad_(True)]
+    outs = ops.joint_attention(pos, qcode, kcode, inv, H, HD, (P, Hs), flat)
+    douts = [rnd(B * P, H * HD, seed=30), rnd(B * Hs, H * HD, seed=31)]
+    valid = pad.view(-1)
+    # gradients arriving at padded query rows are don't-care in the model; zero them for a clean comparison
+    dfull = torch.cat([douts[0].view(B, P, -1), douts[1].view(B, Hs, -1)], 1) * pad[:, :, None]
+    douts = [dfull[:, :P].reshape(B * P, -1).contiguous(), dfull[:, P:].reshape(B * Hs, -1).contiguous()]
+    torch.autograd.backward(list(outs), douts)
+    refs = [t.detach().float().requires_grad_(True) for t in flat]
+    q = torch.cat([refs[0].view(B, P, -1), refs[3].view(B, Hs, -1)], 1)
+    k = torch.cat([refs[1].view(B, P, -1), refs[4].view(B, Hs, -1)], 1)
+    v = torch.cat([refs[2].view(B, P, -1), refs[5].view(B, Hs, -1)], 1)
+    o = _mqa_ref(q, k, v, pos, inv, qcode, kcode, H, HD)
+    o.backward(dfull.float())
+    got = torch.cat([outs[0].view(B, P, -1), outs[1].view(B, Hs, -1)], 1)
+    # fp32 reference vs a path that (like the reference model) rounds logits and probabilities to bf16
+    assert rel_err(got[pad], o[pad]) < 1e-2
+    names = ["dq_p", "dk_p", "dv_p", "dq_s", "dk_s", "dv_s"]
+    for n, t, r in zip(names, flat, refs):
+        e = rel_err(t.grad, r.grad)
+        assert e < 2e-2, f"{n}: rel-L2 {e:.3e}"
+
+
+def test_siglip_attention_fwd_bwd(ops):
+    n, S, NH, HD = 3, 16, 4, 72
+    E = NH * HD
+    q, k, v = (rnd(n * S, E, seed=s).requires_grad_(True) for s in (1, 2, 3))
+    do = rnd(n * S, E, seed=4)
+    out = ops.siglip_attention(q, k, v, n, S, NH, HD)
+    out.backward(do)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    sh = lambda t: t.view(n, S, NH, HD).permute(0, 2, 1, 3)  # noqa: E731
+    p = torch.softmax(sh(qr) @ sh(kr).transpose(-1, -2) * HD**-0.5, -1)
+    o = (p @ sh(vr)).permute(0, 2, 1, 3).reshape(n * S, E)
+    o.backward(do.float())
+    assert rel_err(out, o) < 1e-2
+    for nme, t, r in (("dq", q, qr), ("dk", k, kr), ("dv", v, vr)):
+        e = rel_err(t.grad, r.grad)
+        assert e < 2e-2, f"{nme}: rel-L2 {e:.3e}"
 
 
 def test_embed_and_grad(ops):
@@ -454,8 +537,8 @@ def test_adamw_and_clip(ops):
     for step in range(3):
         for p, r in zip(params, ref):
             g = rnd(*p.shape, dtype=F32, seed=10 + step) * 3
-            p.grad = g.to(p.dtype)
-            r.grad = g.to(p.dtype).float()
+            p.grad = g.to(p.dtype).clone()
+            r.grad = g.to(p.dtype).float().clone()
         norm_ref = torch.nn.utils.clip_grad_norm_(ref, 1.0)
         ropt.step()
         norm = opt.step()

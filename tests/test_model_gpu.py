@@ -60,21 +60,31 @@ def test_backward_matches_oracle_autograd(pair):
     o32(pair["obs"], pair["actions"], pair["noise"], pair["time"]).mean().backward()
     gm = {n: p.grad for n, p in m.named_parameters()}
     go = {n: p.grad for n, p in o32.named_parameters()}
-    checked, worst = 0, (0.0, "")
-    unused = ("lm_head", "language_model.norm.weight")
+    checked, bad, table = 0, [], []
     for n, g in go.items():
-        if any(u in n for u in unused):
-            assert g is None or float(g.abs().max()) == 0.0
+        if g is None:
+            # parameters without a consumer: lm_heads, the prefix final norm, and the last prefix layer's
+            # o_proj / post-attention norm / MLP (nothing reads the prefix after the last joint attention)
+            assert gm[n] is None or float(gm[n].abs().max()) == 0.0, f"{n} must not receive a gradient"
             continue
-        assert g is not None, n
         assert gm[n] is not None, f"no gradient for {n}"
+        if float(g.norm()) < 1e-8:  # mathematically zero (e.g. SigLIP key bias: softmax is shift-invariant)
+            assert float(gm[n].float().norm()) < 1e-4, n
+            continue
         r = rel(gm[n], g)
-        worst = max(worst, (r, n))
+        table.append((r, n, float(g.norm())))
         checked += 1
         # embedding rows touched by few tokens and tiny bias grads are noisier in bf16
         tol = 0.08 if ("embed_tokens" in n or n.endswith("bias") or "position_embedding" in n) else 0.05
-        assert r < tol, f"grad mismatch {n}: rel-L2 {r:.3e}"
-    print(f"checked {checked} gradients, worst rel-L2 {worst[0]:.3e} ({worst[1]})")
+        if r >= tol:
+            bad.append((r, n))
+    table.sort(reverse=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_table.txt", "w") as f:
+        for r, n, gn in table:
+            f.write(f"{r:.3e}  |g|={gn:.3e}  {n}\n")
+    print(f"checked {checked} gradients, worst rel-L2 {table[0][0]:.3e} ({table[0][1]})")
+    assert not bad, f"{len(bad)} gradient mismatches, worst: {sorted(bad, reverse=True)[:5]}"
     assert checked > 100
 
 
