@@ -89,7 +89,8 @@ class GemmTimer:
             s.record()
             r = timer._orig(A, B, out, **kw)
             e.record()
-            timer.events.append((s, e, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1)))
+            timer.events.append((s, e, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1),
+                                 (int(kw.get("a_kc", True)), int(kw.get("b_kc", True)), kw["M"], kw["N"], kw["K"], kw.get("batch", 1))))
             return r
 
         ops.gemm = timed_gemm
@@ -100,9 +101,20 @@ class GemmTimer:
         ops.gemm = self._orig
 
     def summarize(self):
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.events)
-        fl = sum(f for _, _, f in self.events)
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.events)
+        fl = sum(f for _, _, f, _ in self.events)
         return ms, fl, len(self.events)
+
+    def breakdown(self):
+        agg = {}
+        for s, e, f, key in self.events:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+            a[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return [{"a_kc": k[0], "b_kc": k[1], "M": k[2], "N": k[3], "K": k[4], "batch": k[5], "calls": v[0], "ms": v[1],
+                 "tflops": v[2] / v[1] / 1e9} for k, v in rows]
 
 
 def cpu_baseline(budget_s: float = 25.0):
@@ -276,6 +288,9 @@ def main():
                 "executed_gemm_tflop_per_step": gemm_flops / args.steps / 1e12,
                 "step_frac_of_mfma_peak": TRAIN_TFLOP_PER_SAMPLE * B / (ms_per_step / 1e3) / MFMA_BF16_PEAK_TFLOPS,
             }
+            if os.environ.get("KAI0_GEMM_BREAKDOWN"):
+                os.makedirs("gpurun_out", exist_ok=True)
+                json.dump(timer.breakdown(), open("gpurun_out/gemm_breakdown.json", "w"), indent=0)
         if world == 1 and not args.no_latency:
             del trainer
             torch.cuda.empty_cache()

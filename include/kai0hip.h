@@ -88,18 +88,26 @@ typedef struct kai0_gemm_desc {
     const void* residual;
     int64_t ldr;
     int64_t sR1, sR2;
+    /* split-K (wgrad shapes with few output tiles and a long contraction): split_k > 1 cuts K into split_k chunks,
+     * each block writes an f32 partial tile into `workspace` (>= batch*split_k*M*N*4 bytes) and a second kernel
+     * reduces and rounds once to bf16.  Only with the plain epilogue (no bias/act/gate/residual/remap). */
+    int32_t split_k, _pad1;
+    void* workspace;
+    int64_t workspace_bytes;
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
 /* sizeof(kai0_gemm_desc) as compiled: lets a foreign-language binding verify its struct mirror */
 int kai0_gemm_desc_size(void);
 
-/* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C)
+/* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C).
+ * split_k > 1 slices the contraction over grid.z and combines with f32 atomics (summation order, hence the last
+ * bits, then depend on scheduling) — used only for the long-contraction gradient reductions.
  * Replaces the f32 islands: patch-embed conv as im2col GEMM (modeling_siglip.py:220-226), adaRMS
  * `dense` (modeling_gemma.py:83-104), time MLP and action in/out projections
  * (pi0_pytorch.py:100-105,264-297,364-371) and their backward. */
 int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
-                  float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate,
+                  float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int split_k,
                   kai0_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

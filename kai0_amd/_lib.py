@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("out_f32", C.c_int32),
         ("pre_out", c_p), ("gate", c_p), ("gate_rpb", C.c_int32), ("accumulate", C.c_int32),
         ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64), ("sR1", c_i64), ("sR2", c_i64),
+        ("split_k", C.c_int32), ("_pad1", C.c_int32), ("workspace", c_p), ("workspace_bytes", c_i64),
     ]  # fmt: skip
 
 
@@ -44,7 +45,7 @@ _PROTOS: dict[str, list] = {
     "kai0_gemm_desc_size": [],
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
-    "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_p],
+    "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
     "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p],
     "kai0_adarms_fwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p],

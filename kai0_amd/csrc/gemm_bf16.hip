@@ -59,6 +59,7 @@ struct GemmArgs {
     const bf16_t* residual;
     int64_t ldr, sR1, sR2;
     int tiles_m, tiles_n;
+    int split_k, k_chunk;  // split-K: blockIdx.y = z * split_k + s, split s owns k in [s*k_chunk, min(K, (s+1)*k_chunk))
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst_wave_uniform) {
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         tile_m = first_m + in_g % gsz;
         tile_n = in_g / gsz;
     }
-    const int z = blockIdx.y;
+    const int ks_id = blockIdx.y % p.split_k;
+    const int z = blockIdx.y / p.split_k;
+    const int kbeg = ks_id * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
     const int z1 = z / p.batch_inner, z2 = z - z1 * p.batch_inner;
     const bf16_t* __restrict__ Ab = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* __restrict__ Bb = p.B + z1 * p.sB1 + z2 * p.sB2;
@@ -158,15 +162,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * STAGE_BYTES + wave * 4096;
         char* sb = sa + TILE_BYTES;
-        const int k0 = kt * BK;
+        const int k0 = kbeg + kt * BK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16_t* src;
             if constexpr (A_KC) {
-                src = (a_ok[j] && (k0 + a_kchunk) < p.K) ? a_src[j] + k0 : zsrc;
+                src = (a_ok[j] && (k0 + a_kchunk) < kend) ? a_src[j] + k0 : zsrc;
             } else {
                 const int kr = k0 + (wave * 4 + j) * 4 + (lane >> 4);
-                src = (a_ok[j] && kr < p.K) ? a_src[j] + p.amap(kr) * p.lda : zsrc;
+                src = (a_ok[j] && kr < kend) ? a_src[j] + p.amap(kr) * p.lda : zsrc;
             }
             glds16(src, sa + j * 1024);
         }
@@ -174,10 +178,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const bf16_t* src;
             if constexpr (B_KC) {
-                src = (b_ok[j] && (k0 + b_kchunk) < p.K) ? b_src[j] + k0 : zsrc;
+                src = (b_ok[j] && (k0 + b_kchunk) < kend) ? b_src[j] + k0 : zsrc;
             } else {
                 const int kr = k0 + (wave * 4 + j) * 4 + (lane >> 4);
-                src = (b_ok[j] && kr < p.K) ? b_src[j] + p.bmap(kr) * p.ldb : zsrc;
+                src = (b_ok[j] && kr < kend) ? b_src[j] + p.bmap(kr) * p.ldb : zsrc;
             }
             glds16(src, sb + j * 1024);
         }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         }
     };
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (kend - kbeg + BK - 1) / BK;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
-    const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
+    const int64_t cz = p.split_k > 1 ? (int64_t)blockIdx.y * p.M * p.N : z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int ccol = n0 + wn * 64 + (lane & 7) * 8;
     // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
@@ -338,6 +342,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     }
 }
 
+// split-K reduction: out[z][row][col] = bf16( sum_s ws[z*S+s][row][col] )  (f32 partial tiles, N % 8 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out, int M,
+                                                            int N, int S, int64_t ldc, int batch_inner, int64_t sC1,
+                                                            int64_t sC2) {
+    const int z = blockIdx.y;
+    const int z1 = z / batch_inner, z2 = z - z1 * batch_inner;
+    const int n8 = N >> 3;
+    const int64_t total = (int64_t)M * n8;
+    const float* w0 = ws + (int64_t)z * S * M * N;
+    bf16_t* o = out + z1 * sC1 + z2 * sC2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n8;
+        const int col = (int)(i - row * n8) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < S; ++sp) {
+            const float* wp = w0 + ((int64_t)sp * M + row) * N + col;
+            f32x4 a = *reinterpret_cast<const f32x4*>(wp);
+            f32x4 b = *reinterpret_cast<const f32x4*>(wp + 4);
+            acc[0] += a[0]; acc[1] += a[1]; acc[2] += a[2]; acc[3] += a[3];
+            acc[4] += b[0]; acc[5] += b[1]; acc[6] += b[2]; acc[7] += b[3];
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[e]);
+        *reinterpret_cast<bf16x8*>(o + row * ldc + col) = ov;
+    }
+}
+
 }  // namespace
 
 KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
@@ -379,11 +411,33 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
     p.tiles_m = (d->M + BM - 1) / BM;
     p.tiles_n = (d->N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n, batch, 1), block(256, 1, 1);
+    p.split_k = 1;
+    p.k_chunk = d->K;
+    const int split = d->split_k > 1 ? d->split_k : 1;
+    if (split > 1) {
+        KAI0_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (int64_t)batch * split * d->M * d->N * 4,
+                     "kai0_gemm_bf16: split_k=%d needs a workspace of batch*split*M*N*4 bytes", split);
+        KAI0_REQUIRE(!d->bias && !d->gate && !d->residual && !d->pre_out && !d->accumulate && !d->out_f32 && d->act == 0 &&
+                         p.scale == 1.0f && d->c_rpb == 0 && (d->N % 8) == 0,
+                     "kai0_gemm_bf16: split_k needs a plain bf16 epilogue");
+        p.split_k = split;
+        p.k_chunk = ((d->K + split - 1) / split + BK - 1) / BK * BK;
+        p.C = d->workspace;
+        p.out_f32 = 1;
+        p.ldc = d->N;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, batch * p.split_k, 1), block(256, 1, 1);
     hipStream_t s = (hipStream_t)stream;
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
     else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
     else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
-    return kai0_check_launch("kai0_gemm_bf16");
+    int rc = kai0_check_launch("kai0_gemm_bf16");
+    if (rc || split == 1) return rc;
+    const int64_t items = (int64_t)d->M * (d->N / 8);
+    int rb = (int)((items + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, batch, 1), dim3(256), 0, s, (const float*)d->workspace, (bf16_t*)d->C,
+                       d->M, d->N, split, d->ldc, p.batch_inner, d->sC1, d->sC2);
+    return kai0_check_launch("kai0_gemm_bf16(split-K reduce)");
 }

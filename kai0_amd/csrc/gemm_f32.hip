@@ -17,7 +17,7 @@ constexpr int FBM = 64, FBN = 64, FBK = 16, PITCH = 80;
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
                                                        const float* __restrict__ B, int64_t sbk, int64_t sbn,
                                                        float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                       const float* __restrict__ bias, int accumulate) {
+                                                       const float* __restrict__ bias, int accumulate, int k_chunk) {
     __shared__ float As[FBK * PITCH];
     __shared__ float Bs[FBK * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -35,19 +35,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < K; k0 += FBK) {
+    // split-K: grid.z slices own k in [z*k_chunk, min(K, (z+1)*k_chunk)) and combine with f32 atomics
+    const int kbeg = blockIdx.z * k_chunk;
+    const int kstop = min(K, kbeg + k_chunk);
+    const bool split = gridDim.z > 1;
+    for (int k0 = kbeg; k0 < kstop; k0 += FBK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = e * 256 + tid;  // 0..1023
             int m, k;
             if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
             float v = 0.f;
-            if (m0 + m < M && k0 + k < K) v = A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak];
+            if (m0 + m < M && k0 + k < kstop) v = A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak];
             As[k * PITCH + m] = v;
             int n, kb;
             if (b_kfast) { kb = idx & 15; n = idx >> 4; } else { n = idx & 63; kb = idx >> 6; }
             float w = 0.f;
-            if (n0 + n < N && k0 + kb < K) w = B[(int64_t)(k0 + kb) * sbk + (int64_t)(n0 + n) * sbn];
+            if (n0 + n < N && k0 + kb < kstop) w = B[(int64_t)(k0 + kb) * sbk + (int64_t)(n0 + n) * sbn];
             Bs[kb * PITCH + n] = w;
         }
         __syncthreads();
@@ -74,15 +78,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 32 + j * 16 + l15;
             if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+            const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * 32 + i * 16 + 4 * g + r;
                 if (row >= M) continue;
                 float v = acc[i][j][r] + bv;
                 float* cp = C + (int64_t)row * ldc + col;
-                if (accumulate) v += *cp;
-                *cp = v;
+                if (split) {
+                    atomicAdd(cp, v);
+                } else {
+                    if (accumulate) v += *cp;
+                    *cp = v;
+                }
             }
         }
 }
@@ -90,13 +98,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }  // namespace
 
 KAI0_API int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
-                           float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate,
+                           float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int split_k,
                            kai0_stream_t stream) {
     KAI0_REQUIRE(A && B && C, "kai0_gemm_f32: null operand");
     KAI0_REQUIRE(M > 0 && N > 0 && K > 0, "kai0_gemm_f32: empty problem M=%d N=%d K=%d", M, N, K);
-    dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM, 1), block(256, 1, 1);
+    if (split_k < 1) split_k = 1;
+    int k_chunk = ((K + split_k - 1) / split_k + FBK - 1) / FBK * FBK;
+    split_k = (K + k_chunk - 1) / k_chunk;
+    dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM, split_k), block(256, 1, 1);
     KAI0_REQUIRE(grid.y <= 65535, "kai0_gemm_f32: M=%d too large for grid.y", M);
+    if (split_k > 1 && !accumulate) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, (hipStream_t)stream);
+        KAI0_REQUIRE(e == hipSuccess, "kai0_gemm_f32: clearing C failed: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M,
-                       N, K, bias, accumulate);
+                       N, K, bias, accumulate, k_chunk);
     return kai0_check_launch("kai0_gemm_f32");
 }

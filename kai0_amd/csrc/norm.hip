@@ -332,19 +332,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------ column reductions
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int ncols,
-                                                              void* __restrict__ out, int out_f32) {
-    // 64 columns x 4 row-groups per block
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int ncols,
+                                                               void* __restrict__ out, int out_f32) {
+    // 64 columns x 16 row-groups per block; fixed summation order (deterministic)
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (col < ncols)
-        for (int b = rg; b < blocks; b += 4) s += partial[(int64_t)b * ncols + col];
+        for (int b = rg; b < blocks; b += 16) s += partial[(int64_t)b * ncols + col];
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && col < ncols) {
-        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
         if (out_f32) reinterpret_cast<float*>(out)[col] = t;
         else reinterpret_cast<bf16_t*>(out)[col] = f2bf(t);
     }
@@ -441,7 +443,7 @@ KAI0_API int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, co
 KAI0_API int kai0_reduce_partials(const float* partial, int blocks, int ncols, void* out, int out_f32,
                                   kai0_stream_t stream) {
     KAI0_REQUIRE(blocks > 0 && ncols > 0, "kai0_reduce_partials: empty");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial,
                        blocks, ncols, out, out_f32);
     return kai0_check_launch("kai0_reduce_partials");
 }

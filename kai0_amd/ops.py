@@ -24,7 +24,7 @@ from ._lib import GemmDesc
 BF16 = torch.bfloat16
 F32 = torch.float32
 
-NORM_PARTIAL_BLOCKS = 128  # blocks (x4 waves) producing dw partials in norm backward
+NORM_PARTIAL_BLOCKS = 512  # blocks (x4 waves) producing dw partials in norm backward
 COLSUM_BLOCKS = 256
 
 
@@ -52,7 +52,7 @@ def gemm(
     sA=(0, 0), sB=(0, 0), sC=(0, 0), a_map=None, b_map=None, c_map=None, bias: torch.Tensor | None = None,
     scale: float = 1.0, act: int = 0, pre_out: torch.Tensor | None = None, gate: torch.Tensor | None = None,
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
-    accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0,
+    accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -95,8 +95,35 @@ def gemm(
         d.ldr = ldr
         d.sR1, d.sR2 = sR
     d.accumulate = int(accumulate)
+    if split_k > 1:
+        ws = _workspace(batch * split_k * M * N * 4, A.device)
+        d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel()
     _lib.call("kai0_gemm_bf16", C.byref(d), _stream())
     return out
+
+
+_WS: dict = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream): split-K partial tiles.  Stream-ordered reuse is safe because
+    every user (GEMM + its reduce) is enqueued on the same stream before the next user."""
+    key = (device.index, _stream())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
+    """Split-K factor for a GEMM with few 128x128 output tiles and a long contraction: aim at ~2 waves of the 512
+    block slots of the chip (256 CUs x 2 blocks) without making each chunk shorter than 16 K-tiles."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    if tiles >= 384 or K < 4096:
+        return 1
+    s = min(16, max(1, 768 // tiles), K // 1024)
+    return max(1, s)
 
 
 def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None, gate_rpb=0, out=None):
@@ -111,12 +138,15 @@ def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None,
     return (out, pre) if want_pre else out
 
 
-def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=False):
+def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=False, split_k=None):
     for t in (A, Bm, out):
         if not t.is_cuda or t.dtype != F32:
             raise _lib.Kai0HipError("gemm_f32: expected f32 CUDA (HIP) tensors; the product path has no CPU fallback")
+    if split_k is None:  # long contraction, few 64x64 output tiles: spread K over the chip
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        split_k = 1 if (tiles >= 512 or K < 2048) else max(1, min(64, 1024 // tiles, K // 256))
     _lib.call("kai0_gemm_f32", A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, out.data_ptr(), out.stride(0), M, N, K,
-              _p(bias), int(accumulate), _stream())  # fmt: skip
+              _p(bias), int(accumulate), split_k, _stream())  # fmt: skip
     return out
 
 
@@ -155,9 +185,13 @@ class LinearFn(torch.autograd.Function):
             # dx[M,K] = dy[M,N] @ w[N,K]  (A K-contig over N; B stored [N][K] = [contraction][cols])
             gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=BF16, device=x.device)
+            # the sharded trainer publishes each parameter's slice of its flat gradient buffer: write dW there
+            # directly, so no gradient copy is needed afterwards (sharded.py)
+            dst = getattr(w, "_kai0_grad_out", None)
+            dw = dst if (dst is not None and dst.shape == w.shape and dst.dtype == BF16) else torch.empty(
+                (N, K), dtype=BF16, device=x.device)
             # dw[N,K] = dy[M,N]^T @ x[M,K]  (both stored [contraction][cols])
-            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K)
+            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k(N, K, M))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((N,), dtype=ctx.bias_dtype, device=x.device)
             scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=x.device)
@@ -431,6 +465,7 @@ class EmbedFn(torch.autograd.Function):
         _lib.call("kai0_embed_gather", table.data_ptr(), tokens.data_ptr(), out.data_ptr(), Bn, T, D, scale, T * D, 0, D,
                   _stream())  # fmt: skip
         ctx.save_for_backward(tokens)
+        ctx.grad_out = getattr(table, "_kai0_grad_out", None)
         ctx.shape = table.shape
         ctx.scale = scale
         return out
@@ -441,7 +476,11 @@ class EmbedFn(torch.autograd.Function):
         dout = dout.contiguous()
         Bn, T = tokens.shape
         V, D = ctx.shape
-        dtable = torch.zeros((V, D), dtype=BF16, device=dout.device)
+        dst = ctx.grad_out
+        if dst is not None and dst.shape == (V, D) and dst.dtype == BF16:
+            dtable = dst  # pre-zeroed slice of the trainer's flat gradient buffer
+        else:
+            dtable = torch.zeros((V, D), dtype=BF16, device=dout.device)
         _lib.call("kai0_embed_grad", dout.data_ptr(), tokens.data_ptr(), dtable.data_ptr(), Bn, T, D, ctx.scale, T * D, 0,
                   D, _stream())  # fmt: skip
         return dtable, None, None

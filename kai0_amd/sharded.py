@@ -70,7 +70,11 @@ class _Bucket:
             p.data = self.flat_param[o : o + p.numel()].view(p.shape)
         lo = rank * self.shard
         self.param_shard = self.flat_param[lo : lo + self.shard]
-        self.grad_shard = torch.zeros(self.shard, dtype=dtype, device=device)
+        # one GPU: the "shard" is the whole buffer — alias it instead of copying
+        self.grad_shard = self.flat_grad if world == 1 else torch.zeros(self.shard, dtype=dtype, device=device)
+        for p, o in zip(params, self.offsets):
+            # producers that can write a gradient in place (LinearFn wgrad, EmbedFn) pick this up
+            p._kai0_grad_out = self.flat_grad[o : o + p.numel()].view(p.shape)
         self.master = self.param_shard.to(F32).clone()
         self.exp_avg = torch.zeros(self.shard, dtype=F32, device=device)
         self.exp_avg_sq = torch.zeros(self.shard, dtype=F32, device=device)
@@ -121,8 +125,7 @@ class ShardedDataParallel:
     # ------------------------------------------------------------------------------------------ collectives
     def _reduce_scatter_avg(self, b: _Bucket):
         if self.world == 1:
-            b.grad_shard.copy_(b.flat_grad)
-            return None
+            return None  # grad_shard aliases flat_grad
         if self.backend == "nccl":  # RCCL
             return dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         # gloo (CPU tests): no reduce_scatter / AVG — all-reduce then keep the local shard
@@ -145,7 +148,8 @@ class ShardedDataParallel:
     # ------------------------------------------------------------------------------------------------ hooks
     def _on_grad(self, p):
         b, o = self._where[p]
-        b.flat_grad[o : o + p.numel()].copy_(p.grad.reshape(-1))
+        if p.grad.data_ptr() != p._kai0_grad_out.data_ptr():  # not already produced in place
+            b.flat_grad[o : o + p.numel()].copy_(p.grad.reshape(-1))
         p.grad = None
         b.pending -= 1
         if b.pending == 0:

@@ -90,6 +90,20 @@ def test_gemm_tn(ops, M, N, K):
     assert_close_bf16(out, a.float().t() @ b.float(), what=f"TN {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("lay,M,N,K,S", [("TN", 256, 2048, 30976, 8), ("TN", 1152, 1152, 24576, 6), ("NT", 136, 264, 4104, 3),
+                                         ("NN", 200, 136, 1000, 4), ("TN", 72, 256, 1000, 16)])
+def test_gemm_split_k(ops, lay, M, N, K, S):
+    a_kc, b_kc = lay[0] == "N", lay[1] == "T"
+    a = rnd(M, K, seed=1) if a_kc else rnd(K, M, seed=1)
+    b = rnd(N, K, seed=2, scale=0.05) if b_kc else rnd(K, N, seed=2, scale=0.05)
+    out = torch.empty((M, N), dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc, lda=a.shape[1], ldb=b.shape[1], ldc=N, split_k=S)
+    A = a.float() if a_kc else a.float().t()
+    Bm = b.float().t() if b_kc else b.float()
+    assert_close_bf16(out, A @ Bm, what=f"split-K {lay} {M}x{N}x{K}/{S}")
+    assert ops.pick_split_k(256, 2048, 30976) > 1 and ops.pick_split_k(16384, 2048, 30976) == 1
+
+
 def test_gemm_tn_a_only(ops):
     """C = A[K,M]^T @ B[N,K]^T (A contraction-strided, B K-contiguous)."""
     M, N, K = 136, 200, 328
@@ -191,6 +205,10 @@ def test_gemm_f32(ops, M, N, K):
     dw = torch.empty((N, K), dtype=F32, device=dev())
     ops.gemm_f32(dy, 1, N, x, K, 1, dw, N, K, M)
     assert rel_err(dw, dy.double().t() @ x.double()) < 2e-6
+    if K >= 512:
+        out2 = torch.empty((M, N), dtype=F32, device=dev())
+        ops.gemm_f32(x, K, 1, w, 1, K, out2, M, N, K, bias=b, split_k=5)
+        assert rel_err(out2, ref) < 2e-6
 
 
 # --------------------------------------------------------------------------------------------------- norms
