@@ -1,9 +1,13 @@
 // gemm_bf16.hip — the bf16 MFMA GEMM under every Linear and attention matmul of the pi0.5 path.
 //
 // gfx950 design:
-//   * 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA 16x16x32 bf16 tiles.
+//   * two tile configurations of one template: 256x256x64 (8 waves as 2x4, each a 128x64 sub-tile = 8x4 MFMA
+//     16x16x32 tiles; 128 KiB LDS, 1 block/CU) for problems that fill the chip, and 128x128x64 (4 waves, 64x64
+//     each; 64 KiB, 2 blocks/CU) for small ones.  Measured (KAI0_GEMM_ABLATE): the 128x128 kernel is bound by the
+//     L2->LDS staging rate (~14 TB/s chip-wide), not by MFMA or LDS reads, so the lever is bytes staged per
+//     FLOP = tile size; 256x256 halves it.
 //   * operands go HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction), never
-//     through VGPRs; two 32 KiB stages (A+B) double-buffered => 64 KiB/block, 2 blocks per CU.
+//     through VGPRs; two stages (A+B) double-buffered.
 //   * the LDS image is lane-linear (DMA constraint), so the bank-conflict XOR swizzle is applied on the
 //     per-lane GLOBAL source address and undone on the ds_read address (same involution both sides).
 //   * K-contiguous operands are read with ds_read_b128; contraction-strided operands (dgrad's W,
@@ -16,15 +20,11 @@
 //     XCD's L2.
 #include "common.h"
 #include "../../include/kai0hip.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;       // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
-constexpr int GROUP_M = 8;
-
-__device__ __attribute__((aligned(16))) uint32_t kai0_zero16[4] = {0, 0, 0, 0};
+constexpr int BK = 64;
 
 struct RowMap {
     int32_t rpb;
@@ -59,25 +59,52 @@ struct GemmArgs {
     const bf16_t* residual;
     int64_t ldr, sR1, sR2;
     int tiles_m, tiles_n;
+    int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
     int split_k, k_chunk;  // split-K: blockIdx.y = z * split_k + s, split s owns k in [s*k_chunk, min(K, (s+1)*k_chunk))
 };
 
-__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst_wave_uniform) {
-    __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))lds_dst_wave_uniform, 16, 0, 0);
+// LDS-DMA through a raw buffer descriptor: 16 B per lane from base + voff (bytes) to lds_dst + lane*16.  An offset at
+// or beyond the descriptor's 2 GiB range returns zeros — that is how tile edges and the K tail are zero-filled
+// (no second source pointer, no per-lane 64-bit address).
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+constexpr uint32_t OOB = 0x80000000u;
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))lds_dst_wave_uniform, 16, (int)voff, 0, 0, 0);
 }
 
 // Swizzle key of a contraction-strided (MC) tile row r: key(r) = (r & 3) | (((r >> 3) & 1) << 2).
 // It spreads the 8 k-rows that a 32-lane half of ds_read_b64_tr_b16 touches ({0..3, 8..11} + 4h) over the 8
 // distinct 32-B segments of the 256-B bank row.  Both the DMA source address and the read address apply it.
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+// block barrier that does NOT drain the LDS-DMA queue behind the compiler's back: the kernel places its own vmcnt.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);  // keep register-only MFMAs on their side of the barrier (they ignore "memory")
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Block tile = (WM*MT*16) x (WN*NT*16) x 64, WM x WN waves, each wave MT x NT MFMA 16x16x32 tiles.
+template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
+    constexpr int NWAVES = WM * WN;
+    constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
+    constexpr int A_TILE = TBM * 128, B_TILE = TBN * 128;  // bytes: [rows][64] or [64][cols] bf16
+    constexpr int STAGE = A_TILE + B_TILE;
+    constexpr int NA = TBM / 8 / NWAVES;          // A DMA pieces (1 KiB) per wave per K-tile
+    constexpr int NB = TBN / 8 / NWAVES;
+    constexpr int A_ROWB = TBM * 2, B_ROWB = TBN * 2;  // bytes per k-row of a contraction-strided tile (256 / 512)
+    constexpr int A_LPR = A_ROWB / 16, B_LPR = B_ROWB / 16;  // 16-B chunks (= lanes) per such row
+    constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;    // k-rows per DMA piece
+    constexpr int GROUP = TBM == 128 ? 8 : 4;
+    static_assert(NA >= 1 && NB >= 1 && NT == 4 && (MT % 4) == 0, "unsupported tile configuration");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- block -> tile (XCD-aware bijective remap, then grouped raster) -------------------------
     const int nwg = gridDim.x;
@@ -89,10 +116,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     }
     int tile_m, tile_n;
     {
-        const int width = GROUP_M * p.tiles_n;
+        const int width = GROUP * p.tiles_n;
         const int group = pid / width;
-        const int first_m = group * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int first_m = group * GROUP;
+        const int gsz = min(p.tiles_m - first_m, GROUP);
         const int in_g = pid - group * width;
         tile_m = first_m + in_g % gsz;
         tile_n = in_g / gsz;
@@ -104,115 +131,103 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     const int z1 = z / p.batch_inner, z2 = z - z1 * p.batch_inner;
     const bf16_t* __restrict__ Ab = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* __restrict__ Bb = p.B + z1 * p.sB1 + z2 * p.sB2;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(kai0_zero16);
+    const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)OOB, 0x00020000);
 
-    // ---- staging source addresses (per thread: 4 DMA pieces per operand per K-tile) -------------
-    // K-contiguous tile [128 rows][64 k]: piece q=wave*4+j covers rows q*8..q*8+7; lane -> row q*8+(lane>>3),
+    // ---- staging source addresses ----------------------------------------------------------------
+    // K-contiguous tile [rows][64 k] (128-B rows): DMA piece q covers rows q*8..q*8+7; lane -> row q*8+(lane>>3),
     //   16-B slot lane&7 which holds source chunk (lane&7)^(row&7).
-    // contraction-strided tile [64 k][128 cols]: piece q covers k-rows q*4..q*4+3; lane -> k-row q*4+(lane>>4),
-    //   slot lane&15 holding source chunk (lane&15)^(key(row)<<1).
-    const bf16_t* a_src[4];
-    const bf16_t* b_src[4];
-    bool a_ok[4], b_ok[4];
-    int a_kchunk = 0, b_kchunk = 0;  // KC: k offset (elements) of this lane's chunk inside the K-tile
+    // contraction-strided tile [64 k][cols] (256- or 512-B rows): piece q covers RPP k-rows; lane -> k-row
+    //   q*RPP + lane/LPR, slot lane%LPR holding source chunk slot^(key(row)<<1)  (key: see above).
+    uint32_t a_off[NA], b_off[NB];  // byte offsets from the operand base; OOB = this lane's chunk lies outside
+    const int kc_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // KC: k offset (elements) of this lane's chunk in the K-tile
     if constexpr (A_KC) {
-        const int c = (lane & 7) ^ (lane >> 3);
-        a_kchunk = c * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (wave * 4 + j) * 8 + (lane >> 3);
-            const int R = m0 + r;
-            a_ok[j] = R < p.M;
-            a_src[j] = Ab + p.amap(a_ok[j] ? R : 0) * p.lda + c * 8;
+        for (int j = 0; j < NA; ++j) {
+            const int R = m0 + (wave * NA + j) * 8 + (lane >> 3);
+            a_off[j] = R < p.M ? (uint32_t)((p.amap(R) * p.lda + kc_chunk) * 2) : OOB;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = wave * 4 + j;
-            const int key = (lane >> 4) | (((q >> 1) & 1) << 2);
-            const int c = (lane & 15) ^ (key << 1);
-            const int col = m0 + c * 8;
-            a_ok[j] = col < p.M;
-            a_src[j] = Ab + col;  // + stored_row(k)*lda added per K-tile
+        for (int j = 0; j < NA; ++j) {
+            const int r = (wave * NA + j) * A_RPP + lane / A_LPR;
+            const int key = (r & 3) | (((r >> 3) & 1) << 2);
+            const int col = m0 + ((lane % A_LPR) ^ (key << 1)) * 8;
+            a_off[j] = col < p.M ? (uint32_t)(col * 2) : OOB;  // + stored_row(k)*lda*2 added per K-tile
         }
     }
     if constexpr (B_KC) {
-        const int c = (lane & 7) ^ (lane >> 3);
-        b_kchunk = c * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (wave * 4 + j) * 8 + (lane >> 3);
-            const int R = n0 + r;
-            b_ok[j] = R < p.N;
-            b_src[j] = Bb + p.bmap(b_ok[j] ? R : 0) * p.ldb + c * 8;
+        for (int j = 0; j < NB; ++j) {
+            const int R = n0 + (wave * NB + j) * 8 + (lane >> 3);
+            b_off[j] = R < p.N ? (uint32_t)((p.bmap(R) * p.ldb + kc_chunk) * 2) : OOB;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = wave * 4 + j;
-            const int key = (lane >> 4) | (((q >> 1) & 1) << 2);
-            const int c = (lane & 15) ^ (key << 1);
-            const int col = n0 + c * 8;
-            b_ok[j] = col < p.N;
-            b_src[j] = Bb + col;
+        for (int j = 0; j < NB; ++j) {
+            const int r = (wave * NB + j) * B_RPP + lane / B_LPR;
+            const int key = (r & 3) | (((r >> 3) & 1) << 2);
+            const int col = n0 + ((lane % B_LPR) ^ (key << 1)) * 8;
+            b_off[j] = col < p.N ? (uint32_t)(col * 2) : OOB;
         }
     }
+    const uint32_t lda2 = (uint32_t)p.lda * 2, ldb2 = (uint32_t)p.ldb * 2;
 
-    auto stage = [&](int kt, int buf) {
-        char* sa = smem + buf * STAGE_BYTES + wave * 4096;
-        char* sb = sa + TILE_BYTES;
+    auto stage = [&](int kt, int slot) {
+        char* sa = smem + slot * STAGE + wave * (NA * 1024);
+        char* sb = smem + slot * STAGE + A_TILE + wave * (NB * 1024);
         const int k0 = kbeg + kt * BK;
+        const bool kc_in = (k0 + kc_chunk) < kend;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16_t* src;
+        for (int j = 0; j < NA; ++j) {
+            uint32_t off;
             if constexpr (A_KC) {
-                src = (a_ok[j] && (k0 + a_kchunk) < kend) ? a_src[j] + k0 : zsrc;
+                off = kc_in ? a_off[j] + (uint32_t)k0 * 2 : OOB;
             } else {
-                const int kr = k0 + (wave * 4 + j) * 4 + (lane >> 4);
-                src = (a_ok[j] && kr < kend) ? a_src[j] + p.amap(kr) * p.lda : zsrc;
+                const int kr = k0 + (wave * NA + j) * A_RPP + lane / A_LPR;
+                off = kr < kend ? a_off[j] + (uint32_t)p.amap(kr) * lda2 : OOB;
             }
-            glds16(src, sa + j * 1024);
+            glds16(a_rsrc, off, sa + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16_t* src;
+        for (int j = 0; j < NB; ++j) {
+            uint32_t off;
             if constexpr (B_KC) {
-                src = (b_ok[j] && (k0 + b_kchunk) < kend) ? b_src[j] + k0 : zsrc;
+                off = kc_in ? b_off[j] + (uint32_t)k0 * 2 : OOB;
             } else {
-                const int kr = k0 + (wave * 4 + j) * 4 + (lane >> 4);
-                src = (b_ok[j] && kr < kend) ? b_src[j] + p.bmap(kr) * p.ldb : zsrc;
+                const int kr = k0 + (wave * NB + j) * B_RPP + lane / B_LPR;
+                off = kr < kend ? b_off[j] + (uint32_t)p.bmap(kr) * ldb2 : OOB;
             }
-            glds16(src, sb + j * 1024);
+            glds16(b_rsrc, off, sb + j * 1024);
         }
     };
 
     // ---- fragment read offsets (bytes inside an operand tile), fixed per thread -----------------
     const int l15 = lane & 15, g = lane >> 4;
-    // KC: row = w*64 + t*16 + l15 ; chunk = ks*4 + g ; addr = row*128 + ((chunk ^ (row&7)) << 4)
-    // MC: cols n = w*64 + t*16 ; k-row r = ks*32 + 8g + 4h + (l15>>2) ; key = (l15>>2)|((g&1)<<2)
-    //     chunk = n/8 + ((l15&3)>>1) ; addr = r*256 + ((chunk ^ (key<<1)) << 4) + (l15&1)*8
+    // KC: row = w*(T*16) + t*16 + l15 ; chunk = ks*4 + g ; addr = row*128 + ((chunk ^ (row&7)) << 4)
+    // MC: cols n = w*(T*16) + t*16 ; k-row r = ks*32 + 8g + 4h + (l15>>2) ; key = (l15>>2)|((g&1)<<2)
+    //     chunk = n/8 + ((l15&3)>>1) ; addr = r*ROWB + ((chunk ^ (key<<1)) << 4) + (l15&1)*8
     const int mc_keyv = (l15 >> 2) | ((g & 1) << 2);
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto load_frag = [&](const char* tile, bool kc, int wsel, int t, int ks) -> bf16x8 {
+    auto load_frag = [&](const char* tile, bool kc, int rowb, int col0, int ks) -> bf16x8 {
         if (kc) {
-            const int row = wsel * 64 + t * 16 + l15;
+            const int row = col0 + l15;
             const int chunk = ks * 4 + g;
             const int off = row * 128 + ((chunk ^ (row & 7)) << 4);
             return *reinterpret_cast<const bf16x8*>(tile + off);
         } else {
-            const int ncol = wsel * 64 + t * 16;
-            const int chunk = (ncol >> 3) + ((l15 & 3) >> 1);
+            const int chunk = (col0 >> 3) + ((l15 & 3) >> 1);
             const int sw = ((chunk ^ (mc_keyv << 1)) << 4) + (l15 & 1) * 8;
             const int r0 = ks * 32 + 8 * g + (l15 >> 2);
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(tile + r0 * 256 + sw));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(tile + (r0 + 4) * 256 + sw));
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(tile + r0 * rowb + sw));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(tile + (r0 + 4) * rowb + sw));
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
@@ -220,43 +235,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     const int nk = (kend - kbeg + BK - 1) / BK;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    lds_barrier();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* ta = smem + buf * STAGE_BYTES;
-        const char* tb = ta + TILE_BYTES;
+        if (kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
+        const char* ta = smem + buf * STAGE;
+        const char* tb = ta + A_TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 bfr[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = load_frag(ta, A_KC, wm, t, ks);
+            for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bfr[t] = load_frag(tb, B_KC, wn, t, ks);
+            for (int h = 0; h < MT / 4; ++h) {  // A fragments 4 at a time: bounds the live registers of the 8x4 tiling
+                bf16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int t = 0; t < 4; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + (h * 4 + t) * 16, ks);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    // wave-private slab: f32 [64][64] at smem + wave*16 KiB. C layout of a 16x16 tile:
-    // col = lane&15, row = 4*(lane>>4) + reg.
+    // wave-private slab: f32 [64][64] at smem + wave*16 KiB, filled MT/4 times (64 rows of the wave's sub-tile each).
+    // C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg.
     float* slab = reinterpret_cast<float*>(smem + wave * 16384);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-
     const int64_t cz = p.split_k > 1 ? (int64_t)blockIdx.y * p.M * p.N : z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int ccol = n0 + wn * 64 + (lane & 7) * 8;
@@ -278,67 +288,80 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         }
     }
     // f32 output keeps the raw accumulator (no bf16 rounding points): used for gradients that must not be
-    // quantised before a cancelling reduction (softmax backward).
+    // quantised before a cancelling reduction (softmax backward) and for split-K partial tiles.
     const bool rnd = !p.out_f32;
     auto R = [rnd](float x) { return rnd ? rbf(x) : x; };
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int lr = it * 8 + (lane >> 3);
-        const int row = m0 + wm * 64 + lr;
-        if (row >= p.M || !col_ok) continue;
-        const float* sp = slab + lr * 64 + (lane & 7) * 8;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const int64_t orow = p.cmap(row);
+    for (int h = 0; h < MT / 4; ++h) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bias8[e]);
-        if (p.scale != 1.0f) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = R(v[e] * p.scale);
-        }
-        if (p.act == 1) {
-            if (p.pre_out != nullptr) {
-                bf16x8 pv;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
-                *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
+                for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lr = it * 8 + (lane >> 3);
+            const int row = m0 + wm * (MT * 16) + h * 64 + lr;
+            if (row >= p.M || !col_ok) continue;
+            const float* sp = slab + lr * 64 + (lane & 7) * 8;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const int64_t orow = p.cmap(row);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bias8[e]);
+            if (p.scale != 1.0f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = R(v[e] * p.scale);
             }
+            if (p.act == 1) {
+                if (p.pre_out != nullptr) {
+                    bf16x8 pv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
-        }
-        if (p.gate != nullptr) {
-            bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
+                    for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
+                    *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
+                }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = R(v[e] * bf2f(gv[e]));
-        }
-        if (p.residual != nullptr) {
-            bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bf2f(rv[e]));
-        }
-        if (p.out_f32) {
-            float* cp = reinterpret_cast<float*>(p.C) + cz + orow * p.ldc + ccol;
-            if (p.accumulate) {
-                f32x4 o0 = *reinterpret_cast<const f32x4*>(cp);
-                f32x4 o1 = *reinterpret_cast<const f32x4*>(cp + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+                for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
             }
-            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + cz + orow * p.ldc + ccol;
-            if (p.accumulate) {
-                bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
+            if (p.gate != nullptr) {
+                bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bf2f(ov[e]);
+                for (int e = 0; e < 8; ++e) v[e] = R(v[e] * bf2f(gv[e]));
             }
-            bf16x8 ov;
+            if (p.residual != nullptr) {
+                bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
-            *reinterpret_cast<bf16x8*>(cp) = ov;
+                for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bf2f(rv[e]));
+            }
+            if (p.out_f32) {
+                float* cp = reinterpret_cast<float*>(p.C) + cz + orow * p.ldc + ccol;
+                if (p.accumulate) {
+                    f32x4 o0 = *reinterpret_cast<const f32x4*>(cp);
+                    f32x4 o1 = *reinterpret_cast<const f32x4*>(cp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+                }
+                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + cz + orow * p.ldc + ccol;
+                if (p.accumulate) {
+                    bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf2f(ov[e]);
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+                *reinterpret_cast<bf16x8*>(cp) = ov;
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -370,6 +393,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+template <int WM, int WN, int MT, int NT>
+int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
+    constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
+    constexpr int LDS = 2 * (TBM + TBN) * 128;
+    p.tiles_m = (d->M + TBM - 1) / TBM;
+    p.tiles_n = (d->N + TBN - 1) / TBN;
+    dim3 grid(p.tiles_m * p.tiles_n, batch * p.split_k, 1), block(WM * WN * 64, 1, 1);
+#define KAI0_LAUNCH(AK, BK_)                                                                                      \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT>;                                                    \
+        if (!attr_set) {                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+            if (e != hipSuccess) {                                                                                \
+                kai0_set_error("kai0_gemm_bf16: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));      \
+                return -2;                                                                                        \
+            }                                                                                                     \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, p);                                                         \
+    } while (0)
+    if (d->a_kc && d->b_kc) KAI0_LAUNCH(true, true);
+    else if (d->a_kc && !d->b_kc) KAI0_LAUNCH(true, false);
+    else if (!d->a_kc && d->b_kc) KAI0_LAUNCH(false, true);
+    else KAI0_LAUNCH(false, false);
+#undef KAI0_LAUNCH
+    return 0;
+}
+
 }  // namespace
 
 KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
@@ -390,6 +442,16 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
+    {
+        // operands are addressed with 32-bit byte offsets below a 2 GiB buffer descriptor (per batch entry)
+        const int64_t a_rows = d->a_rpb ? ((int64_t)((d->a_kc ? d->M : d->K) / d->a_rpb) + 1) * d->a_bs + d->a_off
+                                        : (d->a_kc ? d->M : d->K);
+        const int64_t b_rows = d->b_rpb ? ((int64_t)((d->b_kc ? d->N : d->K) / d->b_rpb) + 1) * d->b_bs + d->b_off
+                                        : (d->b_kc ? d->N : d->K);
+        KAI0_REQUIRE(a_rows * d->lda * 2 < (int64_t)0x7FFF0000 && b_rows * d->ldb * 2 < (int64_t)0x7FFF0000,
+                     "kai0_gemm_bf16: an operand spans more than 2 GiB per batch entry (A %lld rows, B %lld rows)",
+                     (long long)a_rows, (long long)b_rows);
+    }
     const int batch = d->batch > 0 ? d->batch : 1;
     GemmArgs p;
     p.A = (const bf16_t*)d->A;
@@ -409,8 +471,6 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.gate = (const bf16_t*)d->gate; p.gate_rpb = d->gate_rpb; p.gate_ld = d->gate_ld;
     p.accumulate = d->accumulate;
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
-    p.tiles_m = (d->M + BM - 1) / BM;
-    p.tiles_n = (d->N + BN - 1) / BN;
     p.split_k = 1;
     p.k_chunk = d->K;
     const int split = d->split_k > 1 ? d->split_k : 1;
@@ -426,13 +486,17 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
         p.out_f32 = 1;
         p.ldc = d->N;
     }
-    dim3 grid(p.tiles_m * p.tiles_n, batch * p.split_k, 1), block(256, 1, 1);
+    // tile configuration: 256x256 (1 block of 8 waves per CU, half the staged bytes per FLOP) when the problem gives
+    // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
+    static const int forced = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
+    const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch * (split > 1 ? split : 1);
+    const bool big = forced ? forced == 4 : (big_tiles >= 160 && d->K >= 256);
     hipStream_t s = (hipStream_t)stream;
-    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
-    else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
-    else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
-    int rc = kai0_check_launch("kai0_gemm_bf16");
+    int rc;
+    if (big) rc = launch_cfg<2, 4, 8, 4>(d, p, batch, s);
+    else rc = launch_cfg<2, 2, 4, 4>(d, p, batch, s);
+    if (rc) return rc;
+    rc = kai0_check_launch("kai0_gemm_bf16");
     if (rc || split == 1) return rc;
     const int64_t items = (int64_t)d->M * (d->N / 8);
     int rb = (int)((items + 255) / 256);

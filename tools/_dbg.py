@@ -10,27 +10,10 @@ def timeit(fn, iters=10, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e)/iters
-def run(lay,M,N,K,lda=None,ldb=None):
-    out=torch.empty(M,N,dtype=BF16,device=dev)
-    if lay=='NT':
-        lda=lda or K; ldb=ldb or K
-        a=torch.randn(M,lda,device=dev).to(BF16); b=torch.randn(N,ldb,device=dev).to(BF16); kw=dict(a_kc=True,b_kc=True)
-    elif lay=='NN':
-        lda=lda or K; ldb=ldb or N
-        a=torch.randn(M,lda,device=dev).to(BF16); b=torch.randn(K,ldb,device=dev).to(BF16); kw=dict(a_kc=True,b_kc=False)
-    else:
-        lda=lda or M; ldb=ldb or N
-        a=torch.randn(K,lda,device=dev).to(BF16); b=torch.randn(K,ldb,device=dev).to(BF16); kw=dict(a_kc=False,b_kc=False)
-    ms=timeit(lambda: ops.gemm(a,b,out,M=M,N=N,K=K,lda=lda,ldb=ldb,ldc=N,**kw))
-    print(f'{lay} M={M} N={N} K={K} lda={lda} ldb={ldb}: {ms:.3f} ms {2*M*N*K/ms/1e9:.0f} TF/s',flush=True)
-run('TN',16384,2048,30976)
-run('TN',16384,2048,30976,lda=16384+64,ldb=2048+64)
-run('TN',16384,2048,30976,lda=16384+8,ldb=2048+8)
-run('TN',16384,2048,30976,lda=16384+128,ldb=2048+128)
-run('NN',30976,2048,16384)
-run('NN',30976,2048,16384,ldb=2048+64)
-run('NN',30976,2048,16384,lda=16384+64,ldb=2048+64)
-run('NT',30976,16384,2048)
-run('NT',30976,16384,2048,lda=2048+64,ldb=2048+64)
-run('NT',30976,2048,16384)
-run('NT',30976,2048,16384,lda=16384+64,ldb=16384+64)
+M,N,K=30976,16384,2048
+a=torch.randn(M,K,device=dev).to(BF16); b=torch.randn(N,K,device=dev).to(BF16); out=torch.empty(M,N,dtype=BF16,device=dev)
+ms=timeit(lambda: ops.gemm(a,b,out,M=M,N=N,K=K,lda=K,ldb=K,ldc=N))
+print(f"cfg={os.environ.get('KAI0_GEMM_CFG')} ablate={os.environ.get('KAI0_GEMM_ABLATE')} NT {ms:.3f} ms  {2*M*N*K/ms/1e9:.0f} TF/s-equivalent")
+z=torch.zeros(M,K,device=dev).to(BF16); zb=torch.zeros(N,K,device=dev).to(BF16)
+ms=timeit(lambda: ops.gemm(z,zb,out,M=M,N=N,K=K,lda=K,ldb=K,ldc=N))
+print(f"   zero data: {ms:.3f} ms {2*M*N*K/ms/1e9:.0f}")
