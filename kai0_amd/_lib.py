@@ -70,6 +70,7 @@ _PROTOS: dict[str, list] = {
     "kai0_cast_bf16_to_f32": [c_p, c_p, c_i64, c_p],
     "kai0_add_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "kai0_add_f32": [c_p, c_p, c_p, c_i64, c_p],
+    "kai0_transpose_bf16": [c_p, c_p, c_i, c_i, c_p],
     "kai0_copy_rows_bf16": [c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p],
     "kai0_patch_im2col": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "kai0_add_pos_cast": [c_p, c_p, c_p, c_i64, c_i, c_i, c_p],

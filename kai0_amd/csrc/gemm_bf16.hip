@@ -86,8 +86,11 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Block tile = (WM*MT*16) x (WN*NT*16) x 64, WM x WN waves, each wave MT x NT MFMA 16x16x32 tiles.
-template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT>
+// PP (ping-pong, 8-wave tile only): the waves of tile-row 0 and tile-row 1 (one wave of each per SIMD) run one barrier
+//   slot apart, so in every slot one group issues its 32 MFMAs while the other issues LDS-DMA and ds_reads.
+template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
+    static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
     constexpr int NWAVES = WM * WN;
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
     constexpr int A_TILE = TBM * 128, B_TILE = TBN * 128;  // bytes: [rows][64] or [64][cols] bf16
@@ -233,34 +236,76 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     };
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
-        const char* ta = smem + buf * STAGE;
-        const char* tb = ta + A_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
-#pragma unroll
-            for (int h = 0; h < MT / 4; ++h) {  // A fragments 4 at a time: bounds the live registers of the 8x4 tiling
-                bf16x8 af[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + (h * 4 + t) * 16, ks);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
-            }
-        }
+    if constexpr (PP) {
+        // Barrier clock b0, b1, ...: per K-tile t group 0 runs  L0(t) |b| M0(t) |b| L1(t) |b| M1(t) |b|  and group 1 the same
+        // sequence one barrier later.  Lk = [k = 0: issue the whole DMA of tile t+1] + the 12 fragment reads of k-half
+        // k; Mk = its 32 MFMAs.
+        //  * RAW: tile t+1 is first read after barrier 4t+3 (group 0's L0(t+1)); every wave drains its own DMA before
+        //    that barrier (group 0 at the end of M1(t), group 1 at the end of L1(t)), >= 2 slots after issuing it.
+        //  * WAR: the DMA of tile t+1 overwrites the buffer of tile t-1, last read in group 1's L1(t-1) and retired by
+        //    the lgkmcnt(0) in front of barrier 4t-1; the earliest issue (group 0, L0(t)) comes after that barrier.
+        const int grp = wm;
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
+        if (grp == 1) lds_barrier();  // stagger group 1 by one slot
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const char* ta = smem + buf * STAGE;
+            const char* tb = ta + A_TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 0 && kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
+                bf16x8 bfr[NT], af[MT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + t * 16, ks);
+                if (ks == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (ks == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
+            }
+        }
+        if (grp == 0) lds_barrier();  // re-align the two groups
+    } else {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
+            const char* ta = smem + buf * STAGE;
+            const char* tb = ta + A_TILE;
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bfr[NT];
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
+    #pragma unroll
+                for (int h = 0; h < MT / 4; ++h) {  // A fragments 4 at a time: bounds the live registers of the 8x4 tiling
+                    bf16x8 af[4];
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + (h * 4 + t) * 16, ks);
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -393,7 +438,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, bool PP>
 int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
     constexpr int LDS = 2 * (TBM + TBN) * 128;
@@ -403,7 +448,7 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
 #define KAI0_LAUNCH(AK, BK_)                                                                                      \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
-        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT>;                                                    \
+        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP>;                                                 \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             if (e != hipSuccess) {                                                                                \
@@ -490,11 +535,15 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
     static const int forced = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
     const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch * (split > 1 ? split : 1);
-    const bool big = forced ? forced == 4 : (big_tiles >= 160 && d->K >= 256);
+    const bool big = forced ? forced >= 4 : (big_tiles >= 160 && d->K >= 256);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (big) rc = launch_cfg<2, 4, 8, 4>(d, p, batch, s);
-    else rc = launch_cfg<2, 2, 4, 4>(d, p, batch, s);
+    // measured on the MLP shapes: the ping-pong schedule wins for NT (+3..8 %) and loses for the transpose-read
+    // layouts (their load slot is longer than the MFMA slot), so only NT uses it
+    const bool pp = forced ? forced == 5 : (d->a_kc && d->b_kc);
+    if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
+    else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
+    else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);
     if (rc) return rc;
     rc = kai0_check_launch("kai0_gemm_bf16");
     if (rc || split == 1) return rc;

@@ -182,8 +182,15 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=BF16, device=x.device)
-            # dx[M,K] = dy[M,N] @ w[N,K]  (A K-contig over N; B stored [N][K] = [contraction][cols])
-            gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K)
+            if M >= 4096 and N % 8 == 0 and K % 8 == 0:
+                # many rows: transpose W once (2 x |W| bytes, ~0.2 % of what the GEMM streams) and run dgrad in the
+                # K-contiguous (NT) form, which is ~30 % faster than reading W through ds_read_b64_tr_b16
+                wt = transpose(w)
+                gemm(dy, wt, dx, M=M, N=K, K=N, a_kc=True, b_kc=True, lda=N, ldb=N, ldc=K)
+                del wt
+            else:
+                # dx[M,K] = dy[M,N] @ w[N,K]  (A K-contig over N; B stored [N][K] = [contraction][cols])
+                gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K)
         if ctx.needs_input_grad[1]:
             # the sharded trainer publishes each parameter's slice of its flat gradient buffer: write dW there
             # directly, so no gradient copy is needed afterwards (sharded.py)
@@ -198,6 +205,15 @@ class LinearFn(torch.autograd.Function):
             _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, N, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
                       int(ctx.bias_dtype == F32), _stream())  # fmt: skip
         return dx, dw, db, dres, None
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """bf16 [R, C] -> [C, R] (kai0_transpose_bf16)."""
+    _chk(x, BF16, "transpose.x")
+    R, Cc = x.shape
+    y = torch.empty((Cc, R), dtype=BF16, device=x.device)
+    _lib.call("kai0_transpose_bf16", x.data_ptr(), y.data_ptr(), R, Cc, _stream())
+    return y
 
 
 def linear(x, w, bias=None, residual=None, act=0):

@@ -538,6 +538,22 @@ def test_time_sincos_and_flow(ops):
     assert torch.allclose(xx, xt - 0.1 * ut, atol=1e-6)
 
 
+def test_transpose(ops):
+    for R, Cc in [(64, 64), (2048, 16384), (4304, 1152), (72, 200)]:
+        x = rnd(R, Cc, seed=R)
+        assert torch.equal(ops.transpose(x), x.t().contiguous())
+
+
+def test_linear_autograd_many_rows_uses_transposed_dgrad(ops):
+    M, N, K = 4352, 264, 200
+    x = rnd(M, K, seed=1).requires_grad_(True)
+    w = rnd(N, K, seed=2, scale=0.08).requires_grad_(True)
+    dy = rnd(M, N, seed=5)
+    ops.linear(x, w).backward(dy)
+    assert_close_bf16(x.grad, dy.float() @ w.detach().float(), what="dgrad via W^T", tol=1e-2)
+    assert_close_bf16(w.grad, dy.float().t() @ x.detach().float(), what="wgrad", tol=1e-2)
+
+
 def test_casts(ops):
     x = rnd(1000, 37, dtype=F32, seed=1)
     assert torch.equal(ops.cast(x, BF16), x.to(BF16))
