@@ -88,9 +88,9 @@ typedef struct kai0_gemm_desc {
     const void* residual;
     int64_t ldr;
     int64_t sR1, sR2;
-    /* split-K (wgrad shapes with few output tiles and a long contraction): split_k > 1 cuts K into split_k chunks,
-     * each block writes an f32 partial tile into `workspace` (>= batch*split_k*M*N*4 bytes) and a second kernel
-     * reduces and rounds once to bf16.  Only with the plain epilogue (no bias/act/gate/residual/remap). */
+    /* split-K (few output tiles: long-contraction wgrads, skinny M = 50 inference GEMMs): split_k > 1 cuts K into
+     * split_k chunks, each block writes an f32 partial tile into `workspace` (>= batch*split_k*M*N*4 bytes) and a
+     * second kernel sums them and applies the same fused epilogue once.  Needs N % 8 == 0. */
     int32_t split_k, _pad1;
     void* workspace;
     int64_t workspace_bytes;
@@ -109,6 +109,11 @@ int kai0_gemm_desc_size(void);
 int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                   float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int split_k,
                   kai0_stream_t stream);
+
+/* Few-row f32 Linear, out[m][n] = sum_k x[m][k] W[n][k] + bias[n] for 1 <= M <= 16 (weight-streaming GEMV batch):
+ * the time-MLP and adaRMS `dense` modulations of all denoise steps (M = steps x batch). */
+int kai0_linear_rows_f32(const float* x, const float* W, const float* bias, float* out, int64_t ldo, int M, int N, int K,
+                         kai0_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.

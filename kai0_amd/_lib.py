@@ -46,6 +46,7 @@ _PROTOS: dict[str, list] = {
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
+    "kai0_linear_rows_f32": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
     "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p],
     "kai0_adarms_fwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p],

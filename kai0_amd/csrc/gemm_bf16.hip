@@ -60,6 +60,7 @@ struct GemmArgs {
     int64_t ldr, sR1, sR2;
     int tiles_m, tiles_n;
     int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
+    float* ws;             // split-K workspace [batch*split_k][M][N] f32
     int split_k, k_chunk;  // split-K: blockIdx.y = z * split_k + s, split s owns k in [s*k_chunk, min(K, (s+1)*k_chunk))
 };
 
@@ -75,6 +76,76 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t vof
 // Swizzle key of a contraction-strided (MC) tile row r: key(r) = (r & 3) | (((r >> 3) & 1) << 2).
 // It spreads the 8 k-rows that a 32-lane half of ds_read_b64_tr_b16 touches ({0..3, 8..11} + 4h) over the 8
 // distinct 32-B segments of the 256-B bank row.  Both the DMA source address and the read address apply it.
+
+// The fused epilogue on 8 consecutive columns [ccol, ccol+8) of output row `row` (v = f32 accumulators), shared by the
+// GEMM kernel and the split-K reduction.  Order and rounding points: see kai0hip.h.
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int row, int ccol, int64_t cz, int64_t rz,
+                                          void* cbase, bool raw_f32) {
+    // raw_f32: f32 output keeps the raw accumulator (no bf16 rounding points): gradients that must not be quantised
+    // before a cancelling reduction (softmax backward) and split-K partial tiles.
+    const bool rnd = !raw_f32;
+    auto R = [rnd](float x) { return rnd ? rbf(x) : x; };
+    const int64_t orow = p.cmap(row);
+    if (p.bias != nullptr) {
+        if (p.bias_f32) {
+            const float* bp = reinterpret_cast<const float*>(p.bias) + ccol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bp[e];
+        } else {
+            bf16x8 bv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bias) + ccol);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(bv[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = R(v[e]);
+    if (p.scale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = R(v[e] * p.scale);
+    }
+    if (p.act == 1) {
+        if (p.pre_out != nullptr) {
+            bf16x8 pv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
+    }
+    if (p.gate != nullptr) {
+        bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = R(v[e] * bf2f(gv[e]));
+    }
+    if (p.residual != nullptr) {
+        bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bf2f(rv[e]));
+    }
+    if (raw_f32) {
+        float* cp = reinterpret_cast<float*>(cbase) + cz + orow * p.ldc + ccol;
+        if (p.accumulate) {
+            f32x4 o0 = *reinterpret_cast<const f32x4*>(cp);
+            f32x4 o1 = *reinterpret_cast<const f32x4*>(cp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+        }
+        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(cbase) + cz + orow * p.ldc + ccol;
+        if (p.accumulate) {
+            bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(ov[e]);
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x8*>(cp) = ov;
+    }
+}
 
 // block barrier that does NOT drain the LDS-DMA queue behind the compiler's back: the kernel places its own vmcnt.
 __device__ __forceinline__ void lds_barrier() {
@@ -312,30 +383,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     // wave-private slab: f32 [64][64] at smem + wave*16 KiB, filled MT/4 times (64 rows of the wave's sub-tile each).
     // C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg.
     float* slab = reinterpret_cast<float*>(smem + wave * 16384);
-    const int64_t cz = p.split_k > 1 ? (int64_t)blockIdx.y * p.M * p.N : z1 * p.sC1 + z2 * p.sC2;
+    const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int ccol = n0 + wn * 64 + (lane & 7) * 8;
     // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
     // zero-filled) and are stored into the row padding the host guarantees (ldc >= round_up(N, 8)).
     const bool col_ok = ccol < ((p.N + 7) & ~7);
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (p.bias != nullptr && col_ok) {
-        if (p.bias_f32) {
-            const float* bp = reinterpret_cast<const float*>(p.bias) + ccol;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = bp[e];
-        } else {
-            bf16x8 bv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bias) + ccol);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = bf2f(bv[e]);
-        }
-    }
-    // f32 output keeps the raw accumulator (no bf16 rounding points): used for gradients that must not be
-    // quantised before a cancelling reduction (softmax backward) and for split-K partial tiles.
-    const bool rnd = !p.out_f32;
-    auto R = [rnd](float x) { return rnd ? rbf(x) : x; };
 #pragma unroll
     for (int h = 0; h < MT / 4; ++h) {
 #pragma unroll
@@ -355,54 +408,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
             f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const int64_t orow = p.cmap(row);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bias8[e]);
-            if (p.scale != 1.0f) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = R(v[e] * p.scale);
-            }
-            if (p.act == 1) {
-                if (p.pre_out != nullptr) {
-                    bf16x8 pv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
-                    *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
-            }
-            if (p.gate != nullptr) {
-                bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = R(v[e] * bf2f(gv[e]));
-            }
-            if (p.residual != nullptr) {
-                bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bf2f(rv[e]));
-            }
-            if (p.out_f32) {
-                float* cp = reinterpret_cast<float*>(p.C) + cz + orow * p.ldc + ccol;
-                if (p.accumulate) {
-                    f32x4 o0 = *reinterpret_cast<const f32x4*>(cp);
-                    f32x4 o1 = *reinterpret_cast<const f32x4*>(cp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
-                }
-                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            if (p.split_k > 1) {  // raw f32 partial tile into the workspace; the fused epilogue runs in the reduction
+                float* wp = reinterpret_cast<float*>(p.ws) + ((int64_t)blockIdx.y * p.M + row) * p.N + ccol;
+                *reinterpret_cast<f32x4*>(wp) = v0;
+                *reinterpret_cast<f32x4*>(wp + 4) = v1;
             } else {
-                bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + cz + orow * p.ldc + ccol;
-                if (p.accumulate) {
-                    bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bf2f(ov[e]);
-                }
-                bf16x8 ov;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
-                *reinterpret_cast<bf16x8*>(cp) = ov;
+                epilogue8(p, v, row, ccol, cz, rz, p.C, p.out_f32 != 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -410,31 +421,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     }
 }
 
-// split-K reduction: out[z][row][col] = bf16( sum_s ws[z*S+s][row][col] )  (f32 partial tiles, N % 8 == 0)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out, int M,
-                                                            int N, int S, int64_t ldc, int batch_inner, int64_t sC1,
-                                                            int64_t sC2) {
+// split-K reduction: sum the f32 partial tiles of a (batch entry, 8-column group) and run the fused epilogue once.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int z = blockIdx.y;
-    const int z1 = z / batch_inner, z2 = z - z1 * batch_inner;
-    const int n8 = N >> 3;
-    const int64_t total = (int64_t)M * n8;
-    const float* w0 = ws + (int64_t)z * S * M * N;
-    bf16_t* o = out + z1 * sC1 + z2 * sC2;
+    const int z1 = z / p.batch_inner, z2 = z - z1 * p.batch_inner;
+    const int n8 = (p.N + 7) >> 3;
+    const int64_t total = (int64_t)p.M * n8;
+    const float* w0 = p.ws + (int64_t)z * p.split_k * p.M * p.N;
+    const int64_t cz = z1 * p.sC1 + z2 * p.sC2, rz = z1 * p.sR1 + z2 * p.sR2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / n8;
-        const int col = (int)(i - row * n8) * 8;
+        const int row = (int)(i / n8);
+        const int col = (int)(i - (int64_t)row * n8) * 8;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < S; ++sp) {
-            const float* wp = w0 + ((int64_t)sp * M + row) * N + col;
+        for (int sp = 0; sp < p.split_k; ++sp) {
+            const float* wp = w0 + ((int64_t)sp * p.M + row) * p.N + col;
             f32x4 a = *reinterpret_cast<const f32x4*>(wp);
             f32x4 b = *reinterpret_cast<const f32x4*>(wp + 4);
             acc[0] += a[0]; acc[1] += a[1]; acc[2] += a[2]; acc[3] += a[3];
             acc[4] += b[0]; acc[5] += b[1]; acc[6] += b[2]; acc[7] += b[3];
         }
-        bf16x8 ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[e]);
-        *reinterpret_cast<bf16x8*>(o + row * ldc + col) = ov;
+        epilogue8(p, acc, row, col, cz, rz, p.C, p.out_f32 != 0);
     }
 }
 
@@ -519,17 +525,14 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.split_k = 1;
     p.k_chunk = d->K;
     const int split = d->split_k > 1 ? d->split_k : 1;
+    p.ws = nullptr;
     if (split > 1) {
         KAI0_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (int64_t)batch * split * d->M * d->N * 4,
                      "kai0_gemm_bf16: split_k=%d needs a workspace of batch*split*M*N*4 bytes", split);
-        KAI0_REQUIRE(!d->bias && !d->gate && !d->residual && !d->pre_out && !d->accumulate && !d->out_f32 && d->act == 0 &&
-                         p.scale == 1.0f && d->c_rpb == 0 && (d->N % 8) == 0,
-                     "kai0_gemm_bf16: split_k needs a plain bf16 epilogue");
+        KAI0_REQUIRE((d->N % 8) == 0, "kai0_gemm_bf16: split_k needs N %% 8 == 0");
         p.split_k = split;
         p.k_chunk = ((d->K + split - 1) / split + BK - 1) / BK * BK;
-        p.C = d->workspace;
-        p.out_f32 = 1;
-        p.ldc = d->N;
+        p.ws = (float*)d->workspace;
     }
     // tile configuration: 256x256 (1 block of 8 waves per CU, half the staged bytes per FLOP) when the problem gives
     // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
@@ -550,7 +553,6 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     const int64_t items = (int64_t)d->M * (d->N / 8);
     int rb = (int)((items + 255) / 256);
     if (rb > 2048) rb = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, batch, 1), dim3(256), 0, s, (const float*)d->workspace, (bf16_t*)d->C,
-                       d->M, d->N, split, d->ldc, p.batch_inner, d->sC1, d->sC2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, batch, 1), dim3(256), 0, s, p);
     return kai0_check_launch("kai0_gemm_bf16(split-K reduce)");
 }

@@ -115,3 +115,49 @@ KAI0_API int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float
                        N, K, bias, accumulate, k_chunk);
     return kai0_check_launch("kai0_gemm_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Few-row f32 Linear (M <= 16): out[m][n] = sum_k x[m][k] W[n][k] + b[n] — a weight-streaming GEMV batch.
+// One wave per output column n: the 4 KiB weight row is read once with 16-B loads, the M dot products are finished
+// with a wave reduction.  Used for the time-MLP / adaRMS `dense` modulations of the denoise schedule (M = steps*B).
+namespace {
+constexpr int GEMV_MAXM = 16;
+__global__ __launch_bounds__(256) void gemv_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int64_t ldo, int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[GEMV_MAXM];
+#pragma unroll
+    for (int m = 0; m < GEMV_MAXM; ++m) acc[m] = 0.f;
+    const float* wr = W + (int64_t)n * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+        for (int m = 0; m < GEMV_MAXM; ++m) {
+            if (m < M) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)m * K + k);
+                acc[m] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            }
+        }
+    }
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < GEMV_MAXM; ++m) {
+        if (m < M) {
+            const float t = wave_sum(acc[m]);
+            if (lane == 0) out[(int64_t)m * ldo + n] = t + bv;
+        }
+    }
+}
+}  // namespace
+
+KAI0_API int kai0_linear_rows_f32(const float* x, const float* W, const float* bias, float* out, int64_t ldo, int M, int N,
+                                  int K, kai0_stream_t stream) {
+    KAI0_REQUIRE(M >= 1 && M <= GEMV_MAXM && (K % 4) == 0, "kai0_linear_rows_f32: needs 1 <= M <= 16 and K %% 4 == 0 (M=%d K=%d)",
+                 M, K);
+    KAI0_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0, "kai0_linear_rows_f32: unaligned operands");
+    hipLaunchKernelGGL(gemv_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias, out, ldo, M, N, K);
+    return kai0_check_launch("kai0_linear_rows_f32");
+}

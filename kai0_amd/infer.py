@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .ops import BF16, F32, gemm, round_up
+from .ops import BF16, F32, gemm, pick_split_k, round_up
 
 logger = logging.getLogger("kai0_amd")
 
@@ -89,7 +89,8 @@ class InferenceEngine:
     def _proj_into(self, x, lin, dst, rows_pb: int, row0: int, width: int):
         """dst[b, row0 + r, :width] = (x @ W^T)[b*rows_pb + r]  — GEMM epilogue row remap, no copy."""
         M, K = x.shape
-        gemm(x, lin.weight, dst, M=M, N=width, K=K, lda=K, ldb=K, ldc=width, c_map=(rows_pb, self.S_ld, row0))
+        gemm(x, lin.weight, dst, M=M, N=width, K=K, lda=K, ldb=K, ldc=width, c_map=(rows_pb, self.S_ld, row0),
+             split_k=pick_split_k(M, width, K))
 
     def _oproj(self, lin, rows_pb: int, row0: int, residual, gate=None):
         """y = att_buf[b, row0 + r] @ Wo^T (+gate) + residual, reading the padded buffer through the A row remap."""
@@ -98,7 +99,8 @@ class InferenceEngine:
         N = lin.weight.shape[0]
         out = torch.empty((M, N), dtype=BF16, device=self.dev)
         gemm(self.att_buf, lin.weight, out, M=M, N=N, K=H * HD, lda=H * HD, ldb=H * HD, ldc=N,
-             a_map=(rows_pb, self.S_ld, row0), residual=residual, ldr=N, gate=gate, gate_rpb=rows_pb, gate_ld=N)  # fmt: skip
+             a_map=(rows_pb, self.S_ld, row0), residual=residual, ldr=N, gate=gate, gate_rpb=rows_pb, gate_ld=N,
+             split_k=pick_split_k(M, N, H * HD))  # fmt: skip
         return out
 
     # ------------------------------------------------------------------------------------------------ passes

@@ -117,13 +117,13 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
-    """Split-K factor for a GEMM with few 128x128 output tiles and a long contraction: aim at ~2 waves of the 512
-    block slots of the chip (256 CUs x 2 blocks) without making each chunk shorter than 16 K-tiles."""
+    """Split-K factor for a GEMM with few 128x128 output tiles: spread the contraction over the chip's ~512 block slots
+    (256 CUs x 2 blocks) without making a chunk shorter than 4 K-tiles.  Covers both the long-contraction wgrads
+    (K = B*S) and the skinny weight-streaming GEMMs of B=1 inference (M = 50)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 384 or K < 4096:
+    if tiles >= 384 or K < 512:
         return 1
-    s = min(16, max(1, 768 // tiles), K // 1024)
-    return max(1, s)
+    return max(1, min(16, 768 // tiles, K // 256))
 
 
 def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None, gate_rpb=0, out=None):
@@ -134,7 +134,7 @@ def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None,
         out = torch.empty((M, N), dtype=BF16, device=x.device)
     pre = torch.empty((M, N), dtype=BF16, device=x.device) if want_pre else None
     gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, pre_out=pre, residual=residual, ldr=N,
-         gate=gate, gate_rpb=gate_rpb, gate_ld=N)  # fmt: skip
+         gate=gate, gate_rpb=gate_rpb, gate_ld=N, split_k=pick_split_k(M, N, K))  # fmt: skip
     return (out, pre) if want_pre else out
 
 
@@ -190,7 +190,7 @@ class LinearFn(torch.autograd.Function):
                 del wt
             else:
                 # dx[M,K] = dy[M,N] @ w[N,K]  (A K-contig over N; B stored [N][K] = [contraction][cols])
-                gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K)
+                gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k(M, K, N))
         if ctx.needs_input_grad[1]:
             # the sharded trainer publishes each parameter's slice of its flat gradient buffer: write dW there
             # directly, so no gradient copy is needed afterwards (sharded.py)
@@ -230,7 +230,10 @@ class LinearF32Fn(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[0]
         out = torch.empty((M, N), dtype=F32, device=x.device)
-        gemm_f32(x, K, 1, w, 1, K, out, M, N, K, bias=bias)
+        if M <= 16 and K % 4 == 0:
+            _lib.call("kai0_linear_rows_f32", x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), N, M, N, K, _stream())
+        else:
+            gemm_f32(x, K, 1, w, 1, K, out, M, N, K, bias=bias)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return out

@@ -104,6 +104,24 @@ def test_gemm_split_k(ops, lay, M, N, K, S):
     assert ops.pick_split_k(256, 2048, 30976) > 1 and ops.pick_split_k(16384, 2048, 30976) == 1
 
 
+def test_gemm_split_k_full_epilogue(ops):
+    """Skinny inference shape: M = 50 rows, gate + residual + bias through the split-K reduction, row-remapped output."""
+    B, rpb, N, K, S_ld, row0 = 1, 50, 264, 4096, 64, 8
+    M = B * rpb
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    gate, res, bias = rnd(B, N, seed=5), rnd(M, N, seed=6), rnd(N, seed=7)
+    ref = (x.float() @ w.float().t() + bias.float()).to(BF16).float()
+    ref = (ref * gate.float().repeat_interleave(rpb, 0)).to(BF16).float() + res.float()
+    for S in (1, 7):
+        out = torch.empty((M, N), dtype=BF16, device=dev())
+        ops.gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=res, ldr=N, gate=gate, gate_rpb=rpb,
+                 gate_ld=N, split_k=S)
+        assert_close_bf16(out, ref, what=f"split {S} epilogue")
+    buf = torch.zeros((B, S_ld, N), dtype=BF16, device=dev())
+    ops.gemm(x, w, buf, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, c_map=(rpb, S_ld, row0), split_k=5)
+    assert_close_bf16(buf[:, row0 : row0 + rpb].reshape(M, N), x.float() @ w.float().t(), what="split + c_map")
+
+
 def test_gemm_tn_a_only(ops):
     """C = A[K,M]^T @ B[N,K]^T (A contraction-strided, B K-contiguous)."""
     M, N, K = 136, 200, 328
@@ -283,6 +301,13 @@ def test_linear_autograd(ops):
     assert_close_bf16(w.grad, wr.grad, what="linear dw", tol=1.5e-2)
     assert rel_err(bias.grad, br.grad) < 1e-2
     assert torch.equal(res.grad, dy)
+
+
+def test_linear_rows_f32(ops):
+    for M, N, K in [(10, 3072, 1024), (1, 1024, 1024), (16, 37, 64)]:
+        x, w, b = rnd(M, K, dtype=F32, seed=1), rnd(N, K, dtype=F32, seed=2, scale=0.05), rnd(N, dtype=F32, seed=3)
+        out = ops.linear_f32(x, w, b)
+        assert rel_err(out, x.double() @ w.double().t() + b.double()) < 2e-6
 
 
 def test_linear_f32_autograd(ops):
