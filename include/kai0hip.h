@@ -59,6 +59,10 @@ int kai0_device_info(int device, int* n_cu, int* lds_bytes, char* arch_name64);
  *   v = bf16(v)                          (the Linear / matmul output)
  *   if scale != 1: v = bf16(v * scale)   (attention logits: modeling_gemma.py:243)
  *   if act == 1:   pre_out = v (optional); v = bf16(gelu_tanh(v))   (modeling_siglip.py:428-430)
+ *   if act == 2:   GeGLU forward in the up-projection GEMM (modeling_gemma.py:122-126): v = u; pre_out = u;
+ *                  v = bf16(bf16(gelu_tanh(g)) * u) with g = aux1[row][col]
+ *   if act == 3:   GeGLU backward in the down-projection dgrad: v = dh; pre_out = du = bf16(dh * bf16(gelu_tanh(g)));
+ *                  v = dg = bf16(bf16(dh * u) * gelu_tanh'(g)) with g = aux1, u = aux2
  *   if gate:       v = bf16(v * gate[row / gate_rpb][col])          (_gated_residual, modeling_gemma.py:209-227)
  *   if residual:   v = bf16(v + residual[row][col])
  *   if accumulate: v = v + C_old  (f32 out: exact; bf16 out: rounded once)
@@ -94,6 +98,8 @@ typedef struct kai0_gemm_desc {
     int32_t split_k, _pad1;
     void* workspace;
     int64_t workspace_bytes;
+    const void* aux1; /* act 2/3: bf16 [rows][ldc], addressed like C */
+    const void* aux2; /* act 3 */
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);

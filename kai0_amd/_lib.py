@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("pre_out", c_p), ("gate", c_p), ("gate_rpb", C.c_int32), ("accumulate", C.c_int32),
         ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64), ("sR1", c_i64), ("sR2", c_i64),
         ("split_k", C.c_int32), ("_pad1", C.c_int32), ("workspace", c_p), ("workspace_bytes", c_i64),
+        ("aux1", c_p), ("aux2", c_p),
     ]  # fmt: skip
 
 

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "../../include/kai0hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -52,6 +53,8 @@ struct GemmArgs {
     int act;
     int out_f32;
     bf16_t* pre_out;
+    const bf16_t* aux1;  // act 2/3: gate pre-activation g [M][ldc]
+    const bf16_t* aux2;  // act 3: up projection u [M][ldc]
     const bf16_t* gate;
     int gate_rpb;
     int accumulate;
@@ -112,6 +115,28 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
+    } else if (p.act == 2) {
+        // GeGLU forward fused into the up-projection GEMM: v = u; pre_out <- u; C <- bf16(bf16(gelu(g)) * u)
+        bf16x8 uv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) uv[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = uv;
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.aux1 + cz + orow * p.ldc + ccol);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = R(R(gelu_tanh_f(bf2f(gv[e]))) * v[e]);
+    } else if (p.act == 3) {
+        // GeGLU backward fused into the down-projection dgrad: v = dh; pre_out <- du = bf16(dh * bf16(gelu(g)));
+        // C <- dg = bf16(bf16(dh * u) * gelu'(g))
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.aux1 + cz + orow * p.ldc + ccol);
+        const bf16x8 uv = *reinterpret_cast<const bf16x8*>(p.aux2 + cz + orow * p.ldc + ccol);
+        bf16x8 du;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = bf2f(gv[e]);
+            du[e] = f2bf(v[e] * R(gelu_tanh_f(gg)));
+            v[e] = R(R(v[e] * bf2f(uv[e])) * gelu_tanh_grad_f(gg));
+        }
+        *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = du;
     }
     if (p.gate != nullptr) {
         bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
@@ -389,8 +414,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
     // zero-filled) and are stored into the row padding the host guarantees (ldc >= round_up(N, 8)).
     const bool col_ok = ccol < ((p.N + 7) & ~7);
-#pragma unroll
-    for (int h = 0; h < MT / 4; ++h) {
+    // one 64-row half of the wave's sub-tile at a time; `h` is a compile-time constant so acc[] keeps static indices
+    // (a rolled loop here would turn the accumulators into an indexed array for the whole kernel)
+    auto epi_half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -399,7 +426,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll 1
         for (int it = 0; it < 8; ++it) {
             const int lr = it * 8 + (lane >> 3);
             const int row = m0 + wm * (MT * 16) + h * 64 + lr;
@@ -418,7 +445,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-    }
+    };
+    epi_half(std::integral_constant<int, 0>{});
+    if constexpr (MT / 4 > 1) epi_half(std::integral_constant<int, 1>{});
+    static_assert(MT / 4 <= 2, "extend the epilogue halves");
 }
 
 // split-K reduction: sum the f32 partial tiles of a (batch entry, 8-column group) and run the fused epilogue once.
@@ -493,6 +523,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
+    KAI0_REQUIRE(d->act >= 0 && d->act <= 3, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act < 2 || (d->pre_out && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
+                 "kai0_gemm_bf16: act=%d (fused GeGLU) needs pre_out and aux inputs, bf16 output", d->act);
     {
         // operands are addressed with 32-bit byte offsets below a 2 GiB buffer descriptor (per batch entry)
         const int64_t a_rows = d->a_rpb ? ((int64_t)((d->a_kc ? d->M : d->K) / d->a_rpb) + 1) * d->a_bs + d->a_off
@@ -519,6 +552,8 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.scale = d->scale == 0.0f ? 1.0f : d->scale;
     p.act = d->act; p.out_f32 = d->out_f32;
     p.pre_out = (bf16_t*)d->pre_out;
+    p.aux1 = (const bf16_t*)d->aux1;
+    p.aux2 = (const bf16_t*)d->aux2;
     p.gate = (const bf16_t*)d->gate; p.gate_rpb = d->gate_rpb; p.gate_ld = d->gate_ld;
     p.accumulate = d->accumulate;
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;

@@ -84,7 +84,8 @@ class InferenceEngine:
         _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), scores.data_ptr(), qcode.data_ptr(), kcode.data_ptr(), B,
                   Sq, H, Sk, S_ld, M * S_ld, q0, qcode.stride(0), kcode.stride(0), ops._stream())  # fmt: skip
         gemm(scores, self.v_cache[l], self.att_buf, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD,
-             batch=B, sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD)  # fmt: skip
+             batch=B, sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD,
+             split_k=pick_split_k(M, HD, S_ld, B))  # fmt: skip
 
     def _proj_into(self, x, lin, dst, rows_pb: int, row0: int, width: int):
         """dst[b, row0 + r, :width] = (x @ W^T)[b*rows_pb + r]  — GEMM epilogue row remap, no copy."""

@@ -349,14 +349,13 @@ class PaliGemmaWithExpertModel(nn.Module):
             # prefix: o_proj + residual fused in the GEMM epilogue, then RMSNorm -> GeGLU MLP -> residual
             xp = _lin(att_p, ap.o_proj, residual=xp)
             hp = ops.rmsnorm(xp, lp.post_attention_layernorm.weight, lp.post_attention_layernorm.eps)
-            hp = ops.geglu(_lin(hp, lp.mlp.gate_proj), _lin(hp, lp.mlp.up_proj))
-            xp = _lin(hp, lp.mlp.down_proj, residual=xp)
+            xp = ops.geglu_mlp(hp, lp.mlp.gate_proj.weight, lp.mlp.up_proj.weight, lp.mlp.down_proj.weight, residual=xp)
             # suffix (action expert): gated residuals (modeling_gemma.py:209-227)
             xs = ops.gated_residual(xs, _lin(att_s, ae.o_proj), gate1, Hs)
             mod2 = ops.linear_f32(cond, le.post_attention_layernorm.dense.weight, le.post_attention_layernorm.dense.bias)
             hs, gate2 = ops.adarms(xs, mod2, Hs, le.post_attention_layernorm.eps)
-            hs = ops.geglu(_lin(hs, le.mlp.gate_proj), _lin(hs, le.mlp.up_proj))
-            xs = ops.gated_residual(xs, _lin(hs, le.mlp.down_proj), gate2, Hs)
+            ys = ops.geglu_mlp(hs, le.mlp.gate_proj.weight, le.mlp.up_proj.weight, le.mlp.down_proj.weight)
+            xs = ops.gated_residual(xs, ys, gate2, Hs)
             return xp, xs
 
         xp, xs = prefix, suffix

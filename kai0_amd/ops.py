@@ -53,6 +53,7 @@ def gemm(
     scale: float = 1.0, act: int = 0, pre_out: torch.Tensor | None = None, gate: torch.Tensor | None = None,
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
+    aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -86,6 +87,7 @@ def gemm(
     d.act = act
     d.out_f32 = int(out_f32)
     d.pre_out = _p(pre_out)
+    d.aux1, d.aux2 = _p(aux1), _p(aux2)
     if gate is not None:
         d.gate = gate.data_ptr()
         d.gate_rpb = gate_rpb
@@ -123,6 +125,8 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 384 or K < 512:
         return 1
+    if M <= 128:  # one row of tiles: pure weight streaming, latency-bound -> chunks as short as 2 K-tiles
+        return max(1, min(32, 768 // tiles, K // 128))
     return max(1, min(16, 768 // tiles, K // 256))
 
 
@@ -144,7 +148,7 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=Fals
             raise _lib.Kai0HipError("gemm_f32: expected f32 CUDA (HIP) tensors; the product path has no CPU fallback")
     if split_k is None:  # long contraction, few 64x64 output tiles: spread K over the chip
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        split_k = 1 if (tiles >= 512 or K < 2048) else max(1, min(64, 1024 // tiles, K // 256))
+        split_k = 1 if (tiles >= 512 or K < 512) else max(1, min(64, 1024 // tiles, K // 128))
     _lib.call("kai0_gemm_f32", A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, out.data_ptr(), out.stride(0), M, N, K,
               _p(bias), int(accumulate), split_k, _stream())  # fmt: skip
     return out
@@ -385,6 +389,65 @@ class GegluFn(torch.autograd.Function):
 
 def geglu(g, u):
     return GegluFn.apply(g, u)
+
+
+class GegluMlpFn(torch.autograd.Function):
+    """Gemma MLP `down(gelu_tanh(gate(x)) * up(x)) (+ residual)` (modeling_gemma.py:113-126) as three GEMMs with the
+    GeGLU fused into epilogues: forward in the up-projection GEMM (reads g, writes u and h), backward in the
+    down-projection dgrad (dh never reaches HBM; the epilogue writes dg and du), and the two dgrads into x accumulate in
+    the second GEMM's epilogue instead of a separate add."""
+
+    @staticmethod
+    def forward(ctx, x, wg, wu, wd, residual):
+        _chk(x, BF16, "geglu_mlp.x")
+        M, D = x.shape
+        F = wg.shape[0]
+        g = linear_fwd(x, wg)
+        u = torch.empty((M, F), dtype=BF16, device=x.device)
+        h = torch.empty((M, F), dtype=BF16, device=x.device)
+        gemm(x, wu, h, M=M, N=F, K=D, lda=D, ldb=D, ldc=F, act=2, pre_out=u, aux1=g, split_k=1)
+        out = linear_fwd(h, wd, residual=residual)
+        ctx.save_for_backward(x, wg, wu, wd, g, u, h)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wg, wu, wd, g, u, h = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, D = x.shape
+        F = wg.shape[0]
+        dev = x.device
+
+        def wgrad(dy, inp, w, n, k):
+            dst = getattr(w, "_kai0_grad_out", None)
+            dw = dst if (dst is not None and dst.shape == w.shape and dst.dtype == BF16) else torch.empty(
+                (n, k), dtype=BF16, device=dev)
+            gemm(dy, inp, dw, M=n, N=k, K=M, a_kc=False, b_kc=False, lda=n, ldb=k, ldc=k, split_k=pick_split_k(n, k, M))
+            return dw
+
+        dwd = wgrad(dout, h, wd, D, F) if ctx.needs_input_grad[3] else None
+        # dh = dout @ wd (through wd^T, K-contiguous) with the GeGLU backward in the epilogue: C = dg, pre_out = du
+        dg = torch.empty((M, F), dtype=BF16, device=dev)
+        du = torch.empty((M, F), dtype=BF16, device=dev)
+        wdt = transpose(wd)  # [F, D]
+        gemm(dout, wdt, dg, M=M, N=F, K=D, lda=D, ldb=D, ldc=F, act=3, pre_out=du, aux1=g, aux2=u)
+        del wdt
+        dwg = wgrad(dg, x, wg, F, D) if ctx.needs_input_grad[1] else None
+        dwu = wgrad(du, x, wu, F, D) if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, D), dtype=BF16, device=dev)
+            wgt = transpose(wg)  # [D, F]
+            gemm(dg, wgt, dx, M=M, N=D, K=F, lda=F, ldb=F, ldc=D, split_k=1)
+            wut = transpose(wu)
+            gemm(du, wut, dx, M=M, N=D, K=F, lda=F, ldb=F, ldc=D, accumulate=True, split_k=1)
+            del wgt, wut
+        return dx, dwg, dwu, dwd, (dout if ctx.has_res else None)
+
+
+def geglu_mlp(x, wg, wu, wd, residual=None):
+    return GegluMlpFn.apply(x, wg, wu, wd, residual)
 
 
 class GatedResidualFn(torch.autograd.Function):

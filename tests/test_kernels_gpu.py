@@ -352,6 +352,25 @@ def test_geglu_and_gated_residual(ops):
     assert_close_bf16(gate.grad, gtr.grad, what="gated dgate", tol=1e-2)
 
 
+@pytest.mark.parametrize("M,D,Fd", [(200, 64, 136), (4352, 256, 520)])
+def test_geglu_mlp_fused(ops, M, D, Fd):
+    x = rnd(M, D, seed=1).requires_grad_(True)
+    wg, wu = (rnd(Fd, D, seed=s, scale=0.1).requires_grad_(True) for s in (2, 3))
+    wd = rnd(D, Fd, seed=4, scale=0.1).requires_grad_(True)
+    res = rnd(M, D, seed=5).requires_grad_(True)
+    dy = rnd(M, D, seed=6)
+    out = ops.geglu_mlp(x, wg, wu, wd, res)
+    out.backward(dy)
+    ref_in = [t.detach().float().requires_grad_(True) for t in (x, wg, wu, wd, res)]
+    xr, gr, ur, dr, rr = ref_in
+    ref = (torch.nn.functional.gelu(xr @ gr.t(), approximate="tanh") * (xr @ ur.t())) @ dr.t() + rr
+    ref.backward(dy.float())
+    assert rel_err(out, ref) < 6e-3
+    for n, t, r in zip(("dx", "dwg", "dwu", "dwd"), (x, wg, wu, wd), ref_in):
+        assert rel_err(t.grad, r.grad) < 1.5e-2, f"{n}: {rel_err(t.grad, r.grad):.3e}"
+    assert torch.equal(res.grad, dy)
+
+
 def _rope_ref(x, pos, inv_freq, inverse=False):
     """modeling_gemma.py:149-194 in bf16: x [B, S, H, HD], pos [B, S]."""
     freqs = pos[:, :, None].float() * inv_freq[None, None, :]
