@@ -172,6 +172,22 @@ int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode,
 int kai0_softmax_bwd(const void* probs, const void* dprobs, int dprobs_f32, void* dscores, int64_t rows, int Sk,
                      int64_t ld, float scale, kai0_stream_t stream);
 
+/* Fused attention forward (modeling_gemma.py:230-253; modeling_siglip.py:325-345):
+ *   logits = bf16(bf16(Q K^T) * scale), masked as in kai0_softmax_mask_fwd, P = bf16(softmax_f32(logits)), O = bf16(P V).
+ * Query rows are "folded": row r of a batch entry is head r % H of query position q0 + r / H (H = 1 for plain
+ * multi-head attention addressed through the two-level batch strides).  P (optional, bf16 [rows][ldp] per batch entry,
+ * ldp in [Sk, round_up(Sk,64)], padding columns zero) is written for the GEMM-based backward.  HD <= 256. */
+typedef struct kai0_attn_desc {
+    const void* Q; const void* K; const void* V; void* O; void* P;
+    const int32_t* qcode; const int32_t* kcode;
+    int32_t rows, Sk, HD, H, q0, batch, batch_inner, _pad0;
+    int64_t ldq, ldk, ldv, ldo, ldp;
+    int64_t sQ1, sQ2, sK1, sK2, sV1, sV2, sO1, sO2, sP;
+    int64_t qcode_ld, kcode_ld;
+    float scale; int32_t _pad1;
+} kai0_attn_desc;
+int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces.
  * GeGLU (modeling_gemma.py:122-126): h = bf16( bf16(gelu_tanh(g)) * u ) */

@@ -40,12 +40,27 @@ class GemmDesc(C.Structure):
     ]  # fmt: skip
 
 
+class AttnDesc(C.Structure):
+    """Mirror of `kai0_attn_desc` (include/kai0hip.h)."""
+
+    _fields_ = [
+        ("Q", c_p), ("K", c_p), ("V", c_p), ("O", c_p), ("P", c_p), ("qcode", c_p), ("kcode", c_p),
+        ("rows", C.c_int32), ("Sk", C.c_int32), ("HD", C.c_int32), ("H", C.c_int32), ("q0", C.c_int32),
+        ("batch", C.c_int32), ("batch_inner", C.c_int32), ("_pad0", C.c_int32),
+        ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64), ("ldp", c_i64),
+        ("sQ1", c_i64), ("sQ2", c_i64), ("sK1", c_i64), ("sK2", c_i64), ("sV1", c_i64), ("sV2", c_i64),
+        ("sO1", c_i64), ("sO2", c_i64), ("sP", c_i64), ("qcode_ld", c_i64), ("kcode_ld", c_i64),
+        ("scale", c_f), ("_pad1", C.c_int32),
+    ]  # fmt: skip
+
+
 # name -> argtypes (every function returns int except where noted)
 _PROTOS: dict[str, list] = {
     "kai0_abi_version": [],
     "kai0_gemm_desc_size": [],
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
+    "kai0_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
     "kai0_linear_rows_f32": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],

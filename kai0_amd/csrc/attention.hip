@@ -1,0 +1,367 @@
+// attention.hip — fused attention forward for the pi0.5 path: logits, prefix-LM / padding mask, f32 softmax, P V.
+//
+// Replaces eager_attention_forward (modeling_gemma.py:230-253; modeling_siglip.py:325-345) with its exact rounding
+// points: logits = bf16(bf16(Q K^T) * scale), softmax in f32, P = bf16(softmax), O = bf16(P V).
+//
+// gfx950 design:
+//   * "two-pass" instead of online softmax: pass 1 sweeps the key tiles computing the row max / row sum (Q K^T only),
+//     pass 2 recomputes the logits, writes the FINAL normalised P (which the GEMM-based backward consumes) and
+//     accumulates O with that bf16 P.  No accumulator rescaling, no S x S logits round trip through HBM, and bitwise
+//     the reference's rounding order.  Q K^T is cheap here (1/3 of the MFMAs) and K stays in L2.
+//   * transposed orientation: S^T = K Q^T and O^T = V^T P^T.  The C-layout of S^T (lane = query column, registers =
+//     4 consecutive keys) IS the B-operand layout of the second MFMA, so P never leaves registers; softmax statistics
+//     are per lane (no cross-lane traffic in the key loop); V^T comes from a row-major V tile through
+//     ds_read_b64_tr_b16.
+//   * multi-query folding: the caller presents the H query heads of a position as extra rows (rows = Sq*H), so one
+//     K/V tile in LDS serves all heads.
+//   * block = 4 waves, one per SIMD (512-register budget): each wave owns 32 query rows, Q fragments stay in VGPRs;
+//     K (K-contiguous sub-tiles) and V (contraction-strided tile) arrive by LDS-DMA, double-buffered, zero-filled at
+//     the edges by the buffer descriptor.
+#include "common.h"
+#include "../../include/kai0hip.h"
+#include <limits.h>
+
+namespace {
+
+constexpr uint32_t OOB = 0x80000000u;
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))lds_dst_wave_uniform, 16, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct AttnArgs {
+    const bf16_t* Q;
+    const bf16_t* K;
+    const bf16_t* V;
+    bf16_t* O;
+    bf16_t* P;
+    const int32_t* qcode;
+    const int32_t* kcode;
+    int rows, Sk, HD, H, q0;
+    int64_t ldq, ldk, ldv, ldo, ldp;
+    int batch_inner;
+    int64_t sQ1, sQ2, sK1, sK2, sV1, sV2, sO1, sO2, sP;
+    int64_t qcode_ld, kcode_ld;
+    float scale;
+};
+
+// NKS = number of 64-wide K sub-tiles (HD <= 64*NKS); VC = V tile columns (128 or 256); OMT = VC/16 output d-tiles
+template <int NKS, int VC>
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int OMT = VC / 16;
+    constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
+    constexpr int K_BYTES = NKS * 8192;             // NKS x [64 keys][64 d] bf16
+    constexpr int V_ROWB = VC * 2;                  // bytes per key row of the V tile
+    constexpr int V_BYTES = 64 * V_ROWB;
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int V_LPR = V_ROWB / 16;              // lanes per V row (16 or 32)
+    constexpr int V_RPP = 64 / V_LPR;               // key rows per DMA piece (4 or 2)
+    constexpr int NKP = NKS * 8 / 4;                // K DMA pieces per wave per tile
+    constexpr int NVP = (64 / V_RPP) / 4;           // V DMA pieces per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* pbuf_all = smem + 2 * STAGE;              // 4 waves x [32 rows][64 keys] bf16 (P transposition scratch)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int z = blockIdx.y;
+    const int z1 = z / p.batch_inner, z2 = z - z1 * p.batch_inner;
+    const bf16_t* Qb = p.Q + z1 * p.sQ1 + z2 * p.sQ2;
+    const bf16_t* Kb = p.K + z1 * p.sK1 + z2 * p.sK2;
+    const bf16_t* Vb = p.V + z1 * p.sV1 + z2 * p.sV2;
+    bf16_t* Ob = p.O + z1 * p.sO1 + z2 * p.sO2;
+    bf16_t* Pb = p.P + (int64_t)z * p.sP;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)OOB, 0x00020000);
+    const int row0 = blockIdx.x * 128 + wave * 32;   // first query row of this wave
+    const int ntiles = (p.Sk + 63) / 64;
+    const uint32_t ldk2 = (uint32_t)p.ldk * 2, ldv2 = (uint32_t)p.ldv * 2;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[row][32*ks + 8g .. +8] ----------------
+    bf16x8 qf[2][KSTEPS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int r = row0 + nt * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
+            if (r < p.rows && d < p.HD) v = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)r * p.ldq + d);
+            qf[nt][ks] = v;
+        }
+    }
+    // per-lane query codes (mask): the query position of folded row r is q0 + r / H
+    int qc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int r = row0 + nt * 16 + l15;
+        qc[nt] = INT_MAX;
+        if (p.qcode != nullptr) qc[nt] = r < p.rows ? p.qcode[z1 * p.qcode_ld + p.q0 + r / p.H] : -1;
+    }
+
+    // ---- staging ---------------------------------------------------------------------------------------------------
+    // K sub-tile j (d in [64j, 64j+64)): [64 keys][64 d], 128-B rows, DMA piece = 8 key rows; lane -> key row (lane>>3),
+    //   slot lane&7 holding source chunk (lane&7)^(row&7).
+    // V tile: [64 keys][VC], DMA piece = V_RPP key rows; lane -> row lane/V_LPR, slot lane%V_LPR holding source chunk
+    //   slot ^ ((row&7)<<1)  (the tr reads below touch key rows 4g' .. 4g'+3 per 16-lane group: 8 distinct row&7).
+    const int kc_chunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    auto stage = [&](int kt, int slot, bool with_v) {
+        char* sk = smem + slot * STAGE + wave * (NKP * 1024);
+        char* sv = smem + slot * STAGE + K_BYTES + wave * (NVP * 1024);
+        const int key0 = kt * 64;
+#pragma unroll
+        for (int j = 0; j < NKP; ++j) {
+            const int piece = wave * NKP + j;           // 0 .. NKS*8-1
+            const int sub = piece >> 3, key = key0 + (piece & 7) * 8 + (lane >> 3);
+            const int d = sub * 64 + kc_chunk;
+            const uint32_t off = (key < p.Sk && d < p.HD) ? (uint32_t)key * ldk2 + (uint32_t)d * 2 : OOB;
+            glds16(k_rsrc, off, sk + j * 1024);
+        }
+        if (with_v) {
+#pragma unroll
+            for (int j = 0; j < NVP; ++j) {
+                const int r = (wave * NVP + j) * V_RPP + lane / V_LPR;
+                const int c = (lane % V_LPR) ^ ((r & 7) << 1);
+                const int key = key0 + r;
+                const uint32_t off = (key < p.Sk && c * 8 < p.HD) ? (uint32_t)key * ldv2 + (uint32_t)c * 16 : OOB;
+                glds16(v_rsrc, off, sv + j * 1024);
+            }
+        }
+    };
+
+    // S^T tile of this wave: [64 keys][32 queries] = 4 x 2 MFMA tiles; A = K rows (LDS), B = Q (registers)
+    auto logits = [&](const char* tk, f32x4 (&s)[4][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const char* sub = tk + (ks >> 1) * 8192;
+            const int chunk = (ks & 1) * 4 + g;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = mt * 16 + l15;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sub + row * 128 + ((chunk ^ (row & 7)) << 4));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[nt][ks], s[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+    // logits with the reference's rounding, masked: element (mt, nt, r) is key kt*64 + mt*16 + 4g + r, query column l15
+    auto finish_logits = [&](int kt, f32x4 (&s)[4][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int key = kt * 64 + mt * 16 + 4 * g;
+            int kc[4] = {0, 0, 0, 0};
+            if (p.kcode != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kc[r] = (key + r < p.Sk) ? p.kcode[z1 * p.kcode_ld + key + r] : INT_MAX;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = rbf(rbf(s[mt][nt][r]) * p.scale);
+                    const bool ok = (key + r < p.Sk) && (kc[r] <= qc[nt]);
+                    s[mt][nt][r] = ok ? v : -INFINITY;
+                }
+        }
+    };
+
+    // ================================ pass 1: row max and row sum =====================================================
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    stage(0, 0, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, false);
+        f32x4 s[4][2];
+        logits(smem + buf * STAGE, s);
+        finish_logits(kt, s);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[mt][nt][r]);
+            const float mn = fmaxf(m_run[nt], tmax);
+            if (mn > -INFINITY) {
+                float acc = l_run[nt] * __expf(m_run[nt] - mn);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc += __expf(s[mt][nt][r] - mn);
+                l_run[nt] = acc;
+                m_run[nt] = mn;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+    // combine the 4 lane groups (each saw the keys 4g..4g+3 of every 16-key block) of a query column
+    float inv_l[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float m = m_run[nt], l = l_run[nt];
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+            const float mn = fmaxf(m, mo);
+            if (mn > -INFINITY) l = l * __expf(m - mn) + lo * __expf(mo - mn);
+            m = mn;
+        }
+        m_run[nt] = m;
+        inv_l[nt] = l > 0.f ? 1.0f / l : 0.f;
+    }
+
+    // ================================ pass 2: P and O = P V ===========================================================
+    f32x4 o[OMT][2];
+#pragma unroll
+    for (int mt = 0; mt < OMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char* pbuf = pbuf_all + wave * 4096;
+    stage(0, 0, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, true);
+        const char* tk = smem + buf * STAGE;
+        const char* tv = tk + K_BYTES;
+        f32x4 s[4][2];
+        logits(tk, s);
+        finish_logits(kt, s);
+        // final probabilities, rounded to bf16 exactly once (what the reference multiplies V with)
+        bf16x4 pb[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (m_run[nt] > -INFINITY) ? __expf(s[mt][nt][r] - m_run[nt]) * inv_l[nt] : 0.f;
+                    pb[mt][nt][r] = f2bf(e);
+                }
+        // P tile -> global through a wave-private LDS transposition: write [32 q][64 keys] rows, read 16 B per lane
+        if (p.P != nullptr) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    *reinterpret_cast<bf16x4*>(pbuf + (nt * 16 + l15) * 128 + (mt * 16 + 4 * g) * 2) = pb[mt][nt];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int lr = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                const int r = row0 + lr, key = kt * 64 + c8;
+                if (r < p.rows && key < p.ldp)
+                    *reinterpret_cast<bf16x8*>(Pb + (int64_t)r * p.ldp + key) = *reinterpret_cast<const bf16x8*>(pbuf + lr * 128 + c8 * 2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // O^T += V^T P^T : contraction over the 64 keys in two 32-key steps; step kk uses key blocks 2kk and 2kk+1, lane
+        // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
+            const int r_lo = kk * 32 + 4 * g + (l15 >> 2);   // key row this lane addresses for the transpose read
+            const int r_hi = r_lo + 16;
+#pragma unroll
+            for (int mt = 0; mt < OMT; ++mt) {
+                const int chunk = mt * 2 + ((l15 & 3) >> 1);
+                const int sub = (l15 & 1) * 8;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (LDS_PTR(bf16x4))(tv + r_lo * V_ROWB + ((chunk ^ ((r_lo & 7) << 1)) << 4) + sub));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (LDS_PTR(bf16x4))(tv + r_hi * V_ROWB + ((chunk ^ ((r_hi & 7) << 1)) << 4) + sub));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+    // zero the padding columns [64*ntiles, ldp) of P (none when ldp <= 64*ntiles) — the tiles above already wrote
+    // zeros for keys in [Sk, 64*ntiles)
+    // ---- O: lane (q = l15, g) holds O^T rows d = 16 mt + 4g + r ----------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int r = row0 + nt * 16 + l15;
+        if (r >= p.rows) continue;
+#pragma unroll
+        for (int mt = 0; mt < OMT; ++mt) {
+            const int d = mt * 16 + 4 * g;
+            if (d < p.HD) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[mt][nt][e]);
+                *reinterpret_cast<bf16x4*>(Ob + (int64_t)r * p.ldo + d) = ov;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
+    KAI0_REQUIRE(d != nullptr && d->Q && d->K && d->V && d->O, "kai0_attn_fwd: null operand");
+    KAI0_REQUIRE(d->HD % 8 == 0 && d->HD > 0 && d->HD <= 256, "kai0_attn_fwd: HD=%d unsupported", d->HD);
+    KAI0_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0,
+                 "kai0_attn_fwd: leading dims must be multiples of 8");
+    KAI0_REQUIRE(d->P == nullptr || (d->ldp % 8 == 0 && d->ldp >= d->Sk && d->ldp <= ((d->Sk + 63) / 64) * 64),
+                 "kai0_attn_fwd: ldp=%lld must be a multiple of 8 in [Sk, round_up(Sk, 64)]", (long long)d->ldp);
+    KAI0_REQUIRE((d->qcode == nullptr) == (d->kcode == nullptr), "kai0_attn_fwd: qcode/kcode must both be set");
+    KAI0_REQUIRE(d->H >= 1, "kai0_attn_fwd: H must be >= 1");
+    KAI0_REQUIRE((int64_t)d->Sk * d->ldk * 2 < (int64_t)0x7FFF0000 && (int64_t)d->Sk * d->ldv * 2 < (int64_t)0x7FFF0000,
+                 "kai0_attn_fwd: K/V span more than 2 GiB per batch entry");
+    if (d->rows <= 0 || d->Sk <= 0) return 0;
+    AttnArgs p;
+    p.Q = (const bf16_t*)d->Q; p.K = (const bf16_t*)d->K; p.V = (const bf16_t*)d->V;
+    p.O = (bf16_t*)d->O; p.P = (bf16_t*)d->P;
+    p.qcode = d->qcode; p.kcode = d->kcode;
+    p.rows = d->rows; p.Sk = d->Sk; p.HD = d->HD; p.H = d->H; p.q0 = d->q0;
+    p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo; p.ldp = d->ldp;
+    p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+    p.sQ1 = d->sQ1; p.sQ2 = d->sQ2; p.sK1 = d->sK1; p.sK2 = d->sK2; p.sV1 = d->sV1; p.sV2 = d->sV2;
+    p.sO1 = d->sO1; p.sO2 = d->sO2; p.sP = d->sP;
+    p.qcode_ld = d->qcode_ld; p.kcode_ld = d->kcode_ld;
+    p.scale = d->scale;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    dim3 grid((d->rows + 127) / 128, batch, 1), block(256, 1, 1);
+    hipStream_t s = (hipStream_t)stream;
+#define KAI0_ATTN_LAUNCH(NKS, VC)                                                                                  \
+    do {                                                                                                          \
+        constexpr int LDS = 2 * (NKS * 8192 + 64 * VC * 2) + 4 * 4096;                                            \
+        static bool attr_set = false;                                                                             \
+        auto kern = attn_fwd_kernel<NKS, VC>;                                                                     \
+        if (!attr_set) {                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+            KAI0_REQUIRE(e == hipSuccess, "kai0_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, p);                                                         \
+    } while (0)
+    if (d->HD <= 128) KAI0_ATTN_LAUNCH(2, 128);
+    else KAI0_ATTN_LAUNCH(4, 256);
+#undef KAI0_ATTN_LAUNCH
+    return kai0_check_launch("kai0_attn_fwd");
+}

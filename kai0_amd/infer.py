@@ -78,6 +78,14 @@ class InferenceEngine:
         """masked MQA over the static buffers for query rows [q0, q0+Sq) against key rows [0, Sk)."""
         B, S_ld, H, HD = self.B, self.S_ld, self.H, self.HD
         M = Sq * H
+        if ((M + 127) // 128) * B >= 192:  # enough 128-row blocks to fill the chip: one fused kernel
+            ops.attn_fwd(self.q_buf, self.k_cache[l], self.v_cache[l], self.att_buf, None, rows=M, Sk=Sk, HD=HD, H=H, q0=q0,
+                         batch=B, ldq=HD, ldk=HD, ldv=HD, ldo=HD, sQ=(S_ld * H * HD, 0), sK=(S_ld * HD, 0),
+                         sV=(S_ld * HD, 0), sO=(S_ld * H * HD, 0), qcode=qcode, kcode=kcode, scale=HD**-0.5,
+                         q_off=q0 * H * HD, o_off=q0 * H * HD)
+            return
+        # latency-bound small batch: the key dimension has to be spread over the chip -> logits GEMM (N = keys),
+        # masked softmax, split-K P V GEMM
         scores = torch.empty((B, M, S_ld), dtype=BF16, device=self.dev)
         gemm(self.q_buf, self.k_cache[l], scores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=B,
              sA=(S_ld * H * HD, 0), sB=(S_ld * HD, 0), sC=(M * S_ld, 0), scale=HD**-0.5, a_off_elems=q0 * H * HD)  # fmt: skip

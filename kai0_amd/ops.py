@@ -19,7 +19,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import GemmDesc
+from ._lib import AttnDesc, GemmDesc
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -637,24 +637,39 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H, HD, scale):
-    """Prefix-LM masked multi-query attention over padded buffers (modeling_gemma.py:230-253).
+def attn_fwd(Q, K, V, O, P, *, rows, Sk, HD, H=1, q0=0, batch=1, batch_inner=1, ldq, ldk, ldv, ldo, ldp=0, sQ=(0, 0),
+             sK=(0, 0), sV=(0, 0), sO=(0, 0), sP=0, qcode=None, kcode=None, scale, q_off=0, o_off=0):
+    """kai0_attn_fwd (fused logits + mask + softmax + P V; optional P output for the backward)."""
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = Q.data_ptr() + 2 * q_off, K.data_ptr(), V.data_ptr(), O.data_ptr() + 2 * o_off
+    d.P = _p(P)
+    d.qcode, d.kcode = _p(qcode), _p(kcode)
+    d.rows, d.Sk, d.HD, d.H, d.q0, d.batch, d.batch_inner = rows, Sk, HD, H, q0, batch, batch_inner
+    d.ldq, d.ldk, d.ldv, d.ldo, d.ldp = ldq, ldk, ldv, ldo, ldp
+    d.sQ1, d.sQ2 = sQ
+    d.sK1, d.sK2 = sK
+    d.sV1, d.sV2 = sV
+    d.sO1, d.sO2 = sO
+    d.sP = sP
+    if qcode is not None:
+        d.qcode_ld, d.kcode_ld = qcode.stride(0), kcode.stride(0)
+    d.scale = scale
+    _lib.call("kai0_attn_fwd", C.byref(d), _stream())
 
-    q_all [B, S_ld, H*HD] (query rows q0..q0+Sq used), k_all/v_all [B, S_ld, HD] (rows >= Sk are zero).
-    The H query heads of a position are folded into the GEMM M dimension: Q viewed as [Sq*H, HD] per batch.
-    Returns (att [B, S_ld, H*HD] with rows q0..q0+Sq written, probs [B, Sq*H, S_ld])."""
+
+def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H, HD, scale, want_probs=True):
+    """Prefix-LM masked multi-query attention over padded buffers (modeling_gemma.py:230-253), one fused kernel.
+
+    q_all [B, S_ld, H*HD] (query rows q0..q0+Sq used), k_all/v_all [B, S_ld, HD].  The H query heads of a position
+    are folded into the row dimension: Q viewed as [Sq*H, HD] per batch entry.
+    Returns (att [B, S_ld, H*HD] with rows q0..q0+Sq written, probs [B, Sq*H, S_ld] or None)."""
     dev = q_all.device
     M = Sq * H
-    scores = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
-    gemm(q_all, k_all, scores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
-         sB=(S_ld * HD, 0), sC=(M * S_ld, 0), scale=scale, a_off_elems=q0 * H * HD)  # fmt: skip
-    probs = torch.empty_like(scores)
-    _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), probs.data_ptr(), _p(qcode), _p(kcode), Bn, Sq, H, Sk, S_ld,
-              M * S_ld, q0, qcode.stride(0) if qcode is not None else 0, kcode.stride(0) if kcode is not None else 0,
-              _stream())  # fmt: skip
+    probs = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev) if want_probs else None
     att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-    gemm(probs, v_all, att, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
-         sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD)  # fmt: skip
+    attn_fwd(q_all, k_all, v_all, att, probs, rows=M, Sk=Sk, HD=HD, H=H, q0=q0, batch=Bn, ldq=HD, ldk=HD, ldv=HD, ldo=HD,
+             ldp=S_ld, sQ=(S_ld * H * HD, 0), sK=(S_ld * HD, 0), sV=(S_ld * HD, 0), sO=(S_ld * H * HD, 0), sP=M * S_ld,
+             qcode=qcode, kcode=kcode, scale=scale, q_off=q0 * H * HD, o_off=q0 * H * HD)
     return att, probs
 
 
@@ -760,17 +775,10 @@ class SiglipAttentionFn(torch.autograd.Function):
         E = NH * HD
         S_ld = round_up(S, 8)
         scale = HD**-0.5
-        scores = torch.empty((n_img * NH, S, S_ld), dtype=BF16, device=dev)
-        gemm(q, k, scores, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=n_img * NH, batch_inner=NH,
-             sA=(S * E, HD), sB=(S * E, HD), sC=(NH * S * S_ld, S * S_ld), scale=scale)  # fmt: skip
-        probs = torch.empty_like(scores)
-        if S_ld != S:
-            probs.zero_()
-        _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), probs.data_ptr(), None, None, n_img * NH, S, 1, S, S_ld,
-                  S * S_ld, 0, 0, 0, _stream())  # fmt: skip
+        probs = torch.empty((n_img * NH, S, S_ld), dtype=BF16, device=dev)
         out = torch.empty((n_img * S, E), dtype=BF16, device=dev)
-        gemm(probs, v, out, M=S, N=HD, K=S, a_kc=True, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=n_img * NH,
-             batch_inner=NH, sA=(NH * S * S_ld, S * S_ld), sB=(S * E, HD), sC=(S * E, HD))  # fmt: skip
+        attn_fwd(q, k, v, out, probs, rows=S, Sk=S, HD=HD, H=1, batch=n_img * NH, batch_inner=NH, ldq=E, ldk=E, ldv=E,
+                 ldo=E, ldp=S_ld, sQ=(S * E, HD), sK=(S * E, HD), sV=(S * E, HD), sO=(S * E, HD), sP=S * S_ld, scale=scale)
         ctx.save_for_backward(q, k, v, probs)
         ctx.cfg = (n_img, S, S_ld, NH, HD, scale)
         return out
