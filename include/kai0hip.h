@@ -130,20 +130,23 @@ int kai0_linear_rows_f32(const float* x, const float* W, const float* bias, floa
  * rstd (f32 [rows]) is saved for backward.  */
 int kai0_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int D, float eps,
                      kai0_stream_t stream);
+/* backward kernels take an optional `dres` (bf16 [rows][D]): the gradient arriving at x through its residual branch
+ * is added into dx in the same pass (saves a separate add over the activation). */
 int kai0_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, void* dx,
-                     float* dw_partial, int dw_blocks, int64_t rows, int D, kai0_stream_t stream);
+                     float* dw_partial, int dw_blocks, const void* dres, int64_t rows, int D, kai0_stream_t stream);
 int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gate_out, float* rstd, int64_t rows,
                     int rows_per_batch, int D, float eps, kai0_stream_t stream);
 int kai0_adarms_bwd(const void* dy, const void* dgate, const void* x, const float* mod, const float* rstd,
-                    void* dx, float* dmod, int64_t rows, int rows_per_batch, int D, kai0_stream_t stream);
+                    void* dx, float* dmod, const void* dres, int64_t rows, int rows_per_batch, int D,
+                    kai0_stream_t stream);
 /* LayerNorm over the last dim (modeling_siglip.py:439-441,756): bf16 x, bf16 w/b, f32 statistics. */
 int kai0_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
                        int64_t rows, int D, float eps, kai0_stream_t stream);
 int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
-                       void* dx, float* dwb_partial, int dwb_blocks, int64_t rows, int D,
+                       void* dx, float* dwb_partial, int dwb_blocks, const void* dres, int64_t rows, int D,
                        kai0_stream_t stream);
-/* column sums of per-block partials [blocks][ncols] f32 -> out (bf16 or f32) */
-int kai0_reduce_partials(const float* partial, int blocks, int ncols, void* out, int out_f32,
+/* column sums of per-block partials (f32, `blocks` rows of stride ld, ncols columns) -> out (bf16 or f32) */
+int kai0_reduce_partials(const float* partial, int blocks, int ncols, int64_t ld, void* out, int out_f32,
                          kai0_stream_t stream);
 /* bias gradient: out[n] = sum_m dy[m][n]  (dy bf16 [M][ld], out bf16 or f32) */
 int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,

@@ -64,12 +64,12 @@ _PROTOS: dict[str, list] = {
     "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
     "kai0_linear_rows_f32": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
-    "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p],
+    "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p],
     "kai0_adarms_fwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p],
-    "kai0_adarms_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_adarms_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
     "kai0_layernorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
-    "kai0_layernorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p],
-    "kai0_reduce_partials": [c_p, c_i, c_i, c_p, c_i, c_p],
+    "kai0_layernorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p],
+    "kai0_reduce_partials": [c_p, c_i, c_i, c_i64, c_p, c_i, c_p],
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
     "kai0_softmax_mask_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ rstd_in,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
-                                                          int64_t rows, int D) {
+                                                          const bf16_t* __restrict__ dres, int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
@@ -133,9 +133,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         for (int c = 0; c < MAXC; ++c) {
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
-                float o[8];
+                float o[8], rs[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[c][e] - xh[c][e] * s);
+                for (int e = 0; e < 8; ++e) rs[e] = 0.f;
+                if (dres != nullptr) load8(dres + row * D + ci * 8, rs);  // gradient of the residual branch of x
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[c][e] - xh[c][e] * s) + rs[e];
                 store8(dx + row * D + ci * 8, o);
             }
         }
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void adarms_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dgate,
                                                          const bf16_t* __restrict__ x, const float* __restrict__ mod,
                                                          const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
-                                                         float* __restrict__ dmod, int rpb, int D) {
+                                                         float* __restrict__ dmod, const bf16_t* __restrict__ dres, int rpb,
+                                                         int D) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -189,9 +193,12 @@ __global__ __launch_bounds__(256) void adarms_bwd_kernel(const bf16_t* __restric
         }
         s = block_sum<4>(s, red) / (float)D;
         if (act) {
-            float o[8];
+            float o[8], rs[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[e] - xh[e] * s);
+            for (int e = 0; e < 8; ++e) rs[e] = 0.f;
+            if (dres != nullptr) load8(dres + row * D + tid * 8, rs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[e] - xh[e] * s) + rs[e];
             store8(dx + row * D + tid * 8, o);
         }
     }
@@ -269,7 +276,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const bf16_t* __restrict__ w, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, bf16_t* __restrict__ dx,
-                                                            float* __restrict__ partial, int64_t rows, int D) {
+                                                            float* __restrict__ partial, const bf16_t* __restrict__ dres,
+                                                            int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
@@ -310,9 +318,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         for (int c = 0; c < MAXC; ++c) {
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
-                float o[8];
+                float o[8], rs[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[c][e] - s1 - xh[c][e] * s2);
+                for (int e = 0; e < 8; ++e) rs[e] = 0.f;
+                if (dres != nullptr) load8(dres + row * D + ci * 8, rs);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dxh[c][e] - s1 - xh[c][e] * s2) + rs[e];
                 store8(dx + row * D + ci * 8, o);
             }
         }
@@ -333,14 +344,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 
 // ------------------------------------------------------------------------------------ column reductions
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int blocks, int ncols,
-                                                               void* __restrict__ out, int out_f32) {
+                                                               int64_t ld, void* __restrict__ out, int out_f32) {
     // 64 columns x 16 row-groups per block; fixed summation order (deterministic)
     __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (col < ncols)
-        for (int b = rg; b < blocks; b += 16) s += partial[(int64_t)b * ncols + col];
+        for (int b = rg; b < blocks; b += 16) s += partial[(int64_t)b * ld + col];
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && col < ncols) {
@@ -391,11 +402,12 @@ KAI0_API int kai0_rmsnorm_fwd(const void* x, const float* w, void* y, float* rst
 }
 
 KAI0_API int kai0_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, void* dx,
-                              float* dw_partial, int dw_blocks, int64_t rows, int D, kai0_stream_t stream) {
+                              float* dw_partial, int dw_blocks, const void* dres, int64_t rows, int D,
+                              kai0_stream_t stream) {
     CHECK_D("kai0_rmsnorm_bwd", D);
     KAI0_REQUIRE(dw_blocks > 0, "kai0_rmsnorm_bwd: dw_blocks must be > 0");
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(dw_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, w, rstd, (bf16_t*)dx, dw_partial, rows, D);
+                       (const bf16_t*)x, w, rstd, (bf16_t*)dx, dw_partial, (const bf16_t*)dres, rows, D);
     return kai0_check_launch("kai0_rmsnorm_bwd");
 }
 
@@ -411,13 +423,14 @@ KAI0_API int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gat
 }
 
 KAI0_API int kai0_adarms_bwd(const void* dy, const void* dgate, const void* x, const float* mod, const float* rstd,
-                             void* dx, float* dmod, int64_t rows, int rows_per_batch, int D, kai0_stream_t stream) {
+                             void* dx, float* dmod, const void* dres, int64_t rows, int rows_per_batch, int D,
+                             kai0_stream_t stream) {
     CHECK_D("kai0_adarms_bwd", D);
     KAI0_REQUIRE(rows_per_batch > 0 && rows % rows_per_batch == 0, "kai0_adarms_bwd: rows %% rows_per_batch != 0");
     const int B = (int)(rows / rows_per_batch);
     if (B <= 0) return 0;
     hipLaunchKernelGGL(adarms_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)dgate, (const bf16_t*)x, mod, rstd, (bf16_t*)dx, dmod, rows_per_batch, D);
+                       (const bf16_t*)dgate, (const bf16_t*)x, mod, rstd, (bf16_t*)dx, dmod, (const bf16_t*)dres, rows_per_batch, D);
     return kai0_check_launch("kai0_adarms_bwd");
 }
 
@@ -431,20 +444,20 @@ KAI0_API int kai0_layernorm_fwd(const void* x, const void* w, const void* b, voi
 }
 
 KAI0_API int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
-                                void* dx, float* dwb_partial, int dwb_blocks, int64_t rows, int D,
+                                void* dx, float* dwb_partial, int dwb_blocks, const void* dres, int64_t rows, int D,
                                 kai0_stream_t stream) {
     CHECK_D("kai0_layernorm_bwd", D);
     KAI0_REQUIRE(dwb_blocks > 0, "kai0_layernorm_bwd: dwb_blocks must be > 0");
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(dwb_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dwb_partial, rows, D);
+                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dwb_partial, (const bf16_t*)dres, rows, D);
     return kai0_check_launch("kai0_layernorm_bwd");
 }
 
-KAI0_API int kai0_reduce_partials(const float* partial, int blocks, int ncols, void* out, int out_f32,
+KAI0_API int kai0_reduce_partials(const float* partial, int blocks, int ncols, int64_t ld, void* out, int out_f32,
                                   kai0_stream_t stream) {
     KAI0_REQUIRE(blocks > 0 && ncols > 0, "kai0_reduce_partials: empty");
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial,
-                       blocks, ncols, out, out_f32);
+                       blocks, ncols, ld, out, out_f32);
     return kai0_check_launch("kai0_reduce_partials");
 }
 
@@ -458,5 +471,5 @@ KAI0_API int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, floa
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, M, N, ld, scratch);
     int rc = kai0_check_launch("kai0_colsum_bf16");
     if (rc) return rc;
-    return kai0_reduce_partials(scratch, sb, N, out, out_f32, stream);
+    return kai0_reduce_partials(scratch, sb, N, N, out, out_f32, stream);
 }

@@ -303,12 +303,13 @@ class PaliGemmaWithExpertModel(nn.Module):
                             emb.position_embedding.weight, sc.patch_size)  # fmt: skip
 
         def layer_fn(x, layer):
-            h = ops.layernorm(x, layer.layer_norm1.weight, layer.layer_norm1.bias, layer.layer_norm1.eps)
+            x, h = ops.layernorm_res(x, layer.layer_norm1.weight, layer.layer_norm1.bias, layer.layer_norm1.eps)
             at = layer.self_attn
-            q, k, v = _lin(h, at.q_proj), _lin(h, at.k_proj), _lin(h, at.v_proj)
+            q, k, v = ops.linear_multi(h, [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight],
+                                       [at.q_proj.bias, at.k_proj.bias, at.v_proj.bias])
             a = ops.siglip_attention(q, k, v, n, S, NH, HD)
             x = _lin(a, at.out_proj, residual=x)
-            h = ops.layernorm(x, layer.layer_norm2.weight, layer.layer_norm2.bias, layer.layer_norm2.eps)
+            x, h = ops.layernorm_res(x, layer.layer_norm2.weight, layer.layer_norm2.bias, layer.layer_norm2.eps)
             f = _lin(h, layer.mlp.fc1, act=1)
             return _lin(f, layer.mlp.fc2, residual=x)
 
@@ -339,21 +340,21 @@ class PaliGemmaWithExpertModel(nn.Module):
         inv_freq = lm.rope_inv_freq()
 
         def layer_fn(xp, xs, lp, le):
-            hp = ops.rmsnorm(xp, lp.input_layernorm.weight, lp.input_layernorm.eps)
+            xp, hp = ops.rmsnorm_res(xp, lp.input_layernorm.weight, lp.input_layernorm.eps)
             mod1 = ops.linear_f32(cond, le.input_layernorm.dense.weight, le.input_layernorm.dense.bias)
-            hs, gate1 = ops.adarms(xs, mod1, Hs, le.input_layernorm.eps)
+            xs, hs, gate1 = ops.adarms_res(xs, mod1, Hs, le.input_layernorm.eps)
             ap, ae = lp.self_attn, le.self_attn
-            qkv = (_lin(hp, ap.q_proj), _lin(hp, ap.k_proj), _lin(hp, ap.v_proj),
-                   _lin(hs, ae.q_proj), _lin(hs, ae.k_proj), _lin(hs, ae.v_proj))  # fmt: skip
+            qkv = (*ops.linear_multi(hp, [ap.q_proj.weight, ap.k_proj.weight, ap.v_proj.weight]),
+                   *ops.linear_multi(hs, [ae.q_proj.weight, ae.k_proj.weight, ae.v_proj.weight]))  # fmt: skip
             att_p, att_s = ops.joint_attention(pos, qcode, kcode, inv_freq, H, HD, (P, Hs), qkv)
             # prefix: o_proj + residual fused in the GEMM epilogue, then RMSNorm -> GeGLU MLP -> residual
             xp = _lin(att_p, ap.o_proj, residual=xp)
-            hp = ops.rmsnorm(xp, lp.post_attention_layernorm.weight, lp.post_attention_layernorm.eps)
+            xp, hp = ops.rmsnorm_res(xp, lp.post_attention_layernorm.weight, lp.post_attention_layernorm.eps)
             xp = ops.geglu_mlp(hp, lp.mlp.gate_proj.weight, lp.mlp.up_proj.weight, lp.mlp.down_proj.weight, residual=xp)
             # suffix (action expert): gated residuals (modeling_gemma.py:209-227)
             xs = ops.gated_residual(xs, _lin(att_s, ae.o_proj), gate1, Hs)
             mod2 = ops.linear_f32(cond, le.post_attention_layernorm.dense.weight, le.post_attention_layernorm.dense.bias)
-            hs, gate2 = ops.adarms(xs, mod2, Hs, le.post_attention_layernorm.eps)
+            xs, hs, gate2 = ops.adarms_res(xs, mod2, Hs, le.post_attention_layernorm.eps)
             ys = ops.geglu_mlp(hs, le.mlp.gate_proj.weight, le.mlp.up_proj.weight, le.mlp.down_proj.weight)
             xs = ops.gated_residual(xs, ys, gate2, Hs)
             return xp, xs

@@ -154,6 +154,27 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=Fals
     return out
 
 
+def _grad_dst(param, dtype):
+    """Where a parameter's gradient should be produced: the slice of the trainer's flat gradient buffer published by
+    sharded.py (`_kai0_grad_out`, so no copy is needed afterwards) or a fresh tensor."""
+    dst = getattr(param, "_kai0_grad_out", None)
+    if dst is not None and dst.shape == param.shape and dst.dtype == dtype:
+        return dst
+    return torch.empty(param.shape, dtype=dtype, device=param.device)
+
+
+def _grad_ret(param, g):
+    """What a backward returns for `param`: if `g` was produced in the trainer's flat buffer, tell the trainer (its
+    bucket bookkeeping runs now) and return None, so autograd neither clones nor accumulates it; otherwise g."""
+    if g is None or param is None:
+        return g
+    dst = getattr(param, "_kai0_grad_out", None)
+    if dst is not None and g.data_ptr() == dst.data_ptr():
+        param._kai0_grad_done()
+        return None
+    return g
+
+
 # ----------------------------------------------------------------------------------------- autograd shims
 class LinearFn(torch.autograd.Function):
     """bf16 Linear with fused bias / GELU-tanh / residual epilogue (nn.Linear + F.gelu + `x + y`)."""
@@ -166,6 +187,7 @@ class LinearFn(torch.autograd.Function):
         r = linear_fwd(x, w, bias, residual, act, want_pre=need_pre)
         out, pre = r if need_pre else (r, None)
         ctx.save_for_backward(x, w, pre)
+        ctx.bias = bias  # only its grad destination / dtype are used
         ctx.has_bias = bias is not None
         ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.has_res = residual is not None
@@ -198,17 +220,15 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # the sharded trainer publishes each parameter's slice of its flat gradient buffer: write dW there
             # directly, so no gradient copy is needed afterwards (sharded.py)
-            dst = getattr(w, "_kai0_grad_out", None)
-            dw = dst if (dst is not None and dst.shape == w.shape and dst.dtype == BF16) else torch.empty(
-                (N, K), dtype=BF16, device=x.device)
+            dw = _grad_dst(w, BF16)
             # dw[N,K] = dy[M,N]^T @ x[M,K]  (both stored [contraction][cols])
             gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k(N, K, M))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((N,), dtype=ctx.bias_dtype, device=x.device)
+            db = _grad_dst(ctx.bias, ctx.bias_dtype)
             scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=x.device)
             _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, N, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
                       int(ctx.bias_dtype == F32), _stream())  # fmt: skip
-        return dx, dw, db, dres, None
+        return dx, _grad_ret(w, dw), _grad_ret(ctx.bias, db), dres, None
 
 
 def transpose(x: torch.Tensor) -> torch.Tensor:
@@ -222,6 +242,63 @@ def transpose(x: torch.Tensor) -> torch.Tensor:
 
 def linear(x, w, bias=None, residual=None, act=0):
     return LinearFn.apply(x, w, bias, residual, act)
+
+
+class LinearMultiFn(torch.autograd.Function):
+    """Several Linears of the same input (q/k/v projections): y_i = x W_i^T (+ b_i).  One autograd node, so the input
+    gradient is produced by accumulating the dgrads in the GEMM epilogue instead of separate add passes."""
+
+    @staticmethod
+    def forward(ctx, x, n: int, *wb):
+        _chk(x, BF16, "linear_multi.x")
+        ws, bs = wb[:n], wb[n:]
+        outs = tuple(linear_fwd(x, w, b) for w, b in zip(ws, bs))
+        ctx.save_for_backward(x, *ws)
+        ctx.biases = bs
+        ctx.n = n
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, *ws = ctx.saved_tensors
+        n, bs = ctx.n, ctx.biases
+        M, K = x.shape
+        dev = x.device
+        dws, dbs = [None] * n, [None] * n
+        dx = torch.empty((M, K), dtype=BF16, device=dev) if ctx.needs_input_grad[0] else None
+        first = True
+        for i, (w, b, dy) in enumerate(zip(ws, bs, douts)):
+            if dy is None:
+                continue
+            dy = dy.contiguous()
+            N = w.shape[0]
+            if dx is not None:
+                if M >= 4096 and N % 8 == 0:
+                    wt = transpose(w)
+                    gemm(dy, wt, dx, M=M, N=K, K=N, lda=N, ldb=N, ldc=K, accumulate=not first)
+                    del wt
+                else:
+                    gemm(dy, w, dx, M=M, N=K, K=N, a_kc=True, b_kc=False, lda=N, ldb=K, ldc=K, accumulate=not first)
+                first = False
+            if ctx.needs_input_grad[2 + i]:
+                dw = _grad_dst(w, BF16)
+                gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k(N, K, M))
+                dws[i] = _grad_ret(w, dw)
+            if b is not None and ctx.needs_input_grad[2 + n + i]:
+                db = _grad_dst(b, b.dtype)
+                scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=dev)
+                _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, N, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
+                          int(b.dtype == F32), _stream())  # fmt: skip
+                dbs[i] = _grad_ret(b, db)
+        if dx is not None and first:
+            dx.zero_()
+        return (dx, None, *dws, *dbs)
+
+
+def linear_multi(x, weights, biases=None):
+    n = len(weights)
+    biases = list(biases) if biases is not None else [None] * n
+    return LinearMultiFn.apply(x, n, *weights, *biases)
 
 
 class LinearF32Fn(torch.autograd.Function):
@@ -239,6 +316,7 @@ class LinearF32Fn(torch.autograd.Function):
         else:
             gemm_f32(x, K, 1, w, 1, K, out, M, N, K, bias=bias)
         ctx.save_for_backward(x, w)
+        ctx.bias = bias
         ctx.has_bias = bias is not None
         return out
 
@@ -253,13 +331,13 @@ class LinearF32Fn(torch.autograd.Function):
             dx = torch.empty((M, K), dtype=F32, device=x.device)
             gemm_f32(dout, N, 1, w, K, 1, dx, M, K, N)  # dx[m,k] = sum_n dout[m,n] w[n,k]
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=F32, device=x.device)
+            dw = _grad_dst(w, F32)
             gemm_f32(dout, 1, N, x, K, 1, dw, N, K, M)  # dw[n,k] = sum_m dout[m,n] x[m,k]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((N,), dtype=F32, device=x.device)
+            db = _grad_dst(ctx.bias, F32)
             ones = torch.ones((1, M), dtype=F32, device=x.device)
             gemm_f32(ones, M, 1, dout, N, 1, db.view(1, N), 1, N, M)  # db[n] = sum_m dout[m,n]
-        return dx, dw, db
+        return dx, _grad_ret(w, dw), _grad_ret(ctx.bias, db)
 
 
 def linear_f32(x, w, bias=None):
@@ -267,6 +345,9 @@ def linear_f32(x, w, bias=None):
 
 
 class RMSNormFn(torch.autograd.Function):
+    """(x, y = rmsnorm(x)).  x is handed back as the first output so that the residual branch hangs off THIS node: the
+    backward then receives both gradients and adds them inside the norm-backward kernel (no separate add pass)."""
+
     @staticmethod
     def forward(ctx, x, w, eps: float):
         _chk(x, BF16, "rmsnorm.x")
@@ -276,31 +357,40 @@ class RMSNormFn(torch.autograd.Function):
         rstd = torch.empty((rows,), dtype=F32, device=x.device)
         _lib.call("kai0_rmsnorm_fwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, D, eps, _stream())
         ctx.save_for_backward(x, w, rstd)
-        return y
+        return x.view_as(x), y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dres, dy):
         x, w, rstd = ctx.saved_tensors
-        dy = dy.contiguous()
         rows, D = x.shape
+        if dy is None:
+            return dres, None, None
+        dy = dy.contiguous()
+        dres = dres.contiguous() if dres is not None else None
         dx = torch.empty_like(x)
         nb = NORM_PARTIAL_BLOCKS
         part = torch.empty((nb * 4, D), dtype=F32, device=x.device)
         _lib.call("kai0_rmsnorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                  part.data_ptr(), nb, rows, D, _stream())  # fmt: skip
+                  part.data_ptr(), nb, _p(dres), rows, D, _stream())  # fmt: skip
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((D,), dtype=F32, device=x.device)
-            _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, D, dw.data_ptr(), 1, _stream())
-        return dx, dw, None
+            dw = _grad_dst(w, F32)
+            _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, D, D, dw.data_ptr(), 1, _stream())
+        return dx, _grad_ret(w, dw), None
 
 
-def rmsnorm(x, w, eps=1e-6):
+def rmsnorm_res(x, w, eps=1e-6):
+    """-> (x for the residual branch, rmsnorm(x))."""
     return RMSNormFn.apply(x, w, eps)
 
 
+def rmsnorm(x, w, eps=1e-6):
+    return RMSNormFn.apply(x, w, eps)[1]
+
+
 class AdaRMSFn(torch.autograd.Function):
-    """adaRMSNorm given the precomputed modulation `mod` = dense(cond) [B, 3D] f32. Returns (y, gate)."""
+    """adaRMSNorm given the precomputed modulation `mod` = dense(cond) [B, 3D] f32.  Returns (x, y, gate); x is passed
+    through for the residual branch (see RMSNormFn)."""
 
     @staticmethod
     def forward(ctx, x, mod, rows_per_batch: int, eps: float):
@@ -315,26 +405,37 @@ class AdaRMSFn(torch.autograd.Function):
                   rows_per_batch, D, eps, _stream())  # fmt: skip
         ctx.save_for_backward(x, mod, rstd)
         ctx.rpb = rows_per_batch
-        return y, gate
+        return x.view_as(x), y, gate
 
     @staticmethod
-    def backward(ctx, dy, dgate):
+    def backward(ctx, dres, dy, dgate):
         x, mod, rstd = ctx.saved_tensors
         rows, D = x.shape
+        if dy is None:
+            dy = torch.zeros_like(x)
         dy = dy.contiguous()
         dgate = dgate.contiguous() if dgate is not None else None
+        dres = dres.contiguous() if dres is not None else None
         dx = torch.empty_like(x)
         dmod = torch.empty_like(mod)
         _lib.call("kai0_adarms_bwd", dy.data_ptr(), _p(dgate), x.data_ptr(), mod.data_ptr(), rstd.data_ptr(),
-                  dx.data_ptr(), dmod.data_ptr(), rows, ctx.rpb, D, _stream())  # fmt: skip
+                  dx.data_ptr(), dmod.data_ptr(), _p(dres), rows, ctx.rpb, D, _stream())  # fmt: skip
         return dx, dmod, None, None
 
 
-def adarms(x, mod, rows_per_batch, eps=1e-6):
+def adarms_res(x, mod, rows_per_batch, eps=1e-6):
+    """-> (x for the residual branch, y, gate)."""
     return AdaRMSFn.apply(x, mod, rows_per_batch, eps)
 
 
+def adarms(x, mod, rows_per_batch, eps=1e-6):
+    _, y, gate = AdaRMSFn.apply(x, mod, rows_per_batch, eps)
+    return y, gate
+
+
 class LayerNormFn(torch.autograd.Function):
+    """(x, y = layer_norm(x)); x passed through for the residual branch (see RMSNormFn)."""
+
     @staticmethod
     def forward(ctx, x, w, b, eps: float):
         _chk(x, BF16, "layernorm.x")
@@ -344,26 +445,35 @@ class LayerNormFn(torch.autograd.Function):
         rstd = torch.empty((rows,), dtype=F32, device=x.device)
         _lib.call("kai0_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
                   rstd.data_ptr(), rows, D, eps, _stream())  # fmt: skip
-        ctx.save_for_backward(x, w, mean, rstd)
-        return y
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        return x.view_as(x), y
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w, mean, rstd = ctx.saved_tensors
+    def backward(ctx, dres, dy):
+        x, w, b, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
         dy = dy.contiguous()
+        dres = dres.contiguous() if dres is not None else None
         rows, D = x.shape
         dx = torch.empty_like(x)
         nb = NORM_PARTIAL_BLOCKS
         part = torch.empty((nb * 4, 2 * D), dtype=F32, device=x.device)
         _lib.call("kai0_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                  dx.data_ptr(), part.data_ptr(), nb, rows, D, _stream())  # fmt: skip
-        dwb = torch.empty((2 * D,), dtype=w.dtype, device=x.device)
-        _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, 2 * D, dwb.data_ptr(), int(w.dtype == F32), _stream())
-        return dx, dwb[:D], dwb[D:], None
+                  dx.data_ptr(), part.data_ptr(), nb, _p(dres), rows, D, _stream())  # fmt: skip
+        dw, db = _grad_dst(w, w.dtype), _grad_dst(b, b.dtype)
+        f32 = int(w.dtype == F32)
+        _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, D, 2 * D, dw.data_ptr(), f32, _stream())
+        _lib.call("kai0_reduce_partials", part.data_ptr() + 4 * D, nb * 4, D, 2 * D, db.data_ptr(), f32, _stream())
+        return dx, _grad_ret(w, dw), _grad_ret(b, db), None
+
+
+def layernorm_res(x, w, b, eps=1e-6):
+    return LayerNormFn.apply(x, w, b, eps)
 
 
 def layernorm(x, w, b, eps=1e-6):
-    return LayerNormFn.apply(x, w, b, eps)
+    return LayerNormFn.apply(x, w, b, eps)[1]
 
 
 class GegluFn(torch.autograd.Function):
@@ -420,9 +530,7 @@ class GegluMlpFn(torch.autograd.Function):
         dev = x.device
 
         def wgrad(dy, inp, w, n, k):
-            dst = getattr(w, "_kai0_grad_out", None)
-            dw = dst if (dst is not None and dst.shape == w.shape and dst.dtype == BF16) else torch.empty(
-                (n, k), dtype=BF16, device=dev)
+            dw = _grad_dst(w, BF16)
             gemm(dy, inp, dw, M=n, N=k, K=M, a_kc=False, b_kc=False, lda=n, ldb=k, ldc=k, split_k=pick_split_k(n, k, M))
             return dw
 
@@ -443,7 +551,7 @@ class GegluMlpFn(torch.autograd.Function):
             wut = transpose(wu)
             gemm(du, wut, dx, M=M, N=D, K=F, lda=F, ldb=F, ldc=D, accumulate=True, split_k=1)
             del wgt, wut
-        return dx, dwg, dwu, dwd, (dout if ctx.has_res else None)
+        return dx, _grad_ret(wg, dwg), _grad_ret(wu, dwu), _grad_ret(wd, dwd), (dout if ctx.has_res else None)
 
 
 def geglu_mlp(x, wg, wu, wd, residual=None):
@@ -547,7 +655,7 @@ class EmbedFn(torch.autograd.Function):
         _lib.call("kai0_embed_gather", table.data_ptr(), tokens.data_ptr(), out.data_ptr(), Bn, T, D, scale, T * D, 0, D,
                   _stream())  # fmt: skip
         ctx.save_for_backward(tokens)
-        ctx.grad_out = getattr(table, "_kai0_grad_out", None)
+        ctx.table = table
         ctx.shape = table.shape
         ctx.scale = scale
         return out
@@ -558,14 +666,14 @@ class EmbedFn(torch.autograd.Function):
         dout = dout.contiguous()
         Bn, T = tokens.shape
         V, D = ctx.shape
-        dst = ctx.grad_out
+        dst = getattr(ctx.table, "_kai0_grad_out", None)
         if dst is not None and dst.shape == (V, D) and dst.dtype == BF16:
             dtable = dst  # pre-zeroed slice of the trainer's flat gradient buffer
         else:
             dtable = torch.zeros((V, D), dtype=BF16, device=dout.device)
         _lib.call("kai0_embed_grad", dout.data_ptr(), tokens.data_ptr(), dtable.data_ptr(), Bn, T, D, ctx.scale, T * D, 0,
                   D, _stream())  # fmt: skip
-        return dtable, None, None
+        return _grad_ret(ctx.table, dtable), None, None
 
 
 def embed(table, tokens, scale):
@@ -593,6 +701,7 @@ class PatchEmbedFn(torch.autograd.Function):
         out = torch.empty((rows, D), dtype=BF16, device=img.device)
         _lib.call("kai0_add_pos_cast", pe.data_ptr(), pos.data_ptr(), out.data_ptr(), rows, G * G, D, _stream())
         ctx.save_for_backward(cols)
+        ctx.params = (w, b, pos)
         ctx.dims = (n, G, D, Kd, tuple(w.shape))
         return out
 
@@ -602,21 +711,22 @@ class PatchEmbedFn(torch.autograd.Function):
         n, G, D, Kd, wshape = ctx.dims
         rows = n * G * G
         d32 = cast(dout.contiguous(), F32)
-        dw = torch.empty((D, Kd), dtype=F32, device=dout.device)
+        pw, pb, ppos = ctx.params
+        dw = _grad_dst(pw, F32).view(D, Kd)
         gemm_f32(d32, 1, D, cols, Kd, 1, dw, D, Kd, rows)  # dw[d,k] = sum_r d32[r,d] cols[r,k]
-        db = torch.empty((D,), dtype=F32, device=dout.device)
+        db = _grad_dst(pb, F32)
         ones = torch.ones((1, rows), dtype=F32, device=dout.device)
         gemm_f32(ones, rows, 1, d32, D, 1, db.view(1, D), 1, D, rows)
         # dpos[p,d] = sum_n d32[n*G*G + p, d]
         GG = G * G
-        dpos = torch.empty((GG, D), dtype=F32, device=dout.device)
+        dpos = _grad_dst(ppos, F32)
         if n == 1:
             dpos.copy_(d32)
         else:
             ones_n = torch.ones((1, n), dtype=F32, device=dout.device)
             # view d32 as [n][GG*D]: dpos_flat[j] = sum_n d32[n, j]
             gemm_f32(ones_n, n, 1, d32.view(n, GG * D), GG * D, 1, dpos.view(1, GG * D), 1, GG * D, n)
-        return None, dw.view(wshape), db, dpos, None
+        return None, _grad_ret(pw, dw.view(wshape)), _grad_ret(pb, db), _grad_ret(ppos, dpos), None
 
 
 def patch_embed(img, w, b, pos, patch):

@@ -26,6 +26,8 @@ from __future__ import annotations
 
 import math
 
+import functools
+
 import torch
 import torch.distributed as dist
 
@@ -79,6 +81,7 @@ class _Bucket:
         self.exp_avg = torch.zeros(self.shard, dtype=F32, device=device)
         self.exp_avg_sq = torch.zeros(self.shard, dtype=F32, device=device)
         self.pending = len(params)
+        self.arrived = set()
         self.work = None
 
 
@@ -118,6 +121,7 @@ class ShardedDataParallel:
             for p, o in zip(b.params, b.offsets):
                 self._where[p] = (b, o)
                 p.register_post_accumulate_grad_hook(self._on_grad)
+                p._kai0_grad_done = functools.partial(self._on_grad_inplace, p)
         self._sumsq = torch.zeros(1, dtype=F32, device=self.device)
         self._coef = torch.ones(1, dtype=F32, device=self.device)
         self._norm = torch.zeros(1, dtype=F32, device=self.device)
@@ -147,10 +151,25 @@ class ShardedDataParallel:
 
     # ------------------------------------------------------------------------------------------------ hooks
     def _on_grad(self, p):
+        """post-accumulate-grad hook: a gradient that autograd materialised in p.grad (ops that do not know about the
+        flat buffer, e.g. plain torch modules) is copied into the parameter's slice."""
+        if p.grad is None:  # the producer returned None: either _on_grad_inplace already ran, or there is no gradient
+            return
         b, o = self._where[p]
-        if p.grad.data_ptr() != p._kai0_grad_out.data_ptr():  # not already produced in place
-            b.flat_grad[o : o + p.numel()].copy_(p.grad.reshape(-1))
+        b.flat_grad[o : o + p.numel()].copy_(p.grad.reshape(-1))
         p.grad = None
+        self._arrived(p, b)
+
+    def _on_grad_inplace(self, p):
+        """called by the backward shims (ops._grad_ret) after they wrote the gradient straight into p._kai0_grad_out;
+        they then return None to autograd, so no clone, no accumulate and no hook happen for this parameter."""
+        self._arrived(p, self._where[p][0])
+
+    def _arrived(self, p, b):
+        if id(p) in b.arrived:
+            raise RuntimeError("a parameter received two gradients in one step: the in-place gradient path supports "
+                               "one use per parameter per backward")  # fmt: skip
+        b.arrived.add(id(p))
         b.pending -= 1
         if b.pending == 0:
             b.work = self._reduce_scatter_avg(b)  # overlaps with the rest of backward
@@ -187,6 +206,7 @@ class ShardedDataParallel:
                 w.wait()
         for b in self.buckets:
             b.pending = len(b.params)
+            b.arrived.clear()
             b.flat_grad.zero_()
         return self._norm
 

@@ -284,6 +284,31 @@ def test_layernorm_fwd_bwd(ops, rows, D):
     assert rel_err(w.grad, wr.grad) < 1e-2 and rel_err(b.grad, br.grad) < 1e-2
 
 
+def test_norm_residual_passthrough_and_linear_multi(ops):
+    """x feeds a norm AND a residual: one backward kernel returns dres + dnorm; q/k/v dgrads accumulate in the epilogue."""
+    rows, D = 300, 136
+    x = rnd(rows, D, seed=1).requires_grad_(True)
+    w = rnd(D, dtype=F32, seed=2, scale=0.3).requires_grad_(True)
+    ws = [rnd(n, D, seed=3 + i, scale=0.1).requires_grad_(True) for i, n in enumerate((136, 72, 72))]
+    bs = [rnd(n, seed=7 + i).requires_grad_(True) for i, n in enumerate((136, 72, 72))]
+    xr_, h = ops.rmsnorm_res(x, w, 1e-6)
+    q, k, v = ops.linear_multi(h, ws, bs)
+    out = xr_ + q  # residual branch + a consumer
+    douts = [rnd(rows, 136, seed=11), rnd(rows, 72, seed=12), rnd(rows, 72, seed=13)]
+    torch.autograd.backward([out, k, v], douts)
+    X = x.detach().float().requires_grad_(True)
+    W = w.detach().clone().requires_grad_(True)
+    Ws = [t.detach().float().requires_grad_(True) for t in ws]
+    Bs = [t.detach().float().requires_grad_(True) for t in bs]
+    H = X * torch.rsqrt(X.pow(2).mean(-1, keepdim=True) + 1e-6) * (1 + W)
+    Q, K_, V = (H @ Ws[i].t() + Bs[i] for i in range(3))
+    torch.autograd.backward([X + Q, K_, V], [d.float() for d in douts])
+    assert_close_bf16(x.grad, X.grad, what="dres + dnorm", tol=1.5e-2)
+    assert rel_err(w.grad, W.grad) < 1e-2
+    for a, r in zip(ws + bs, Ws + Bs):
+        assert rel_err(a.grad, r.grad) < 1.5e-2
+
+
 def test_linear_autograd(ops):
     M, N, K = 264, 328, 200
     x = rnd(M, K, seed=1).requires_grad_(True)
