@@ -106,6 +106,76 @@ int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
 /* sizeof(kai0_gemm_desc) as compiled: lets a foreign-language binding verify its struct mirror */
 int kai0_gemm_desc_size(void);
 
+/* ------------------------------------------------------------------------------------------------
+ * Few-row weight-streaming GEMM for the denoise loop (B*action_horizon <= a few 64-row tiles):
+ *   C[M, N] = A[M, K] @ W[N, K]^T, bf16 in, f32 accumulate, with the neighbouring element-wise ops fused.
+ * Replaces, per expert layer and denoise step (gemma_pytorch.py:150-279, modeling_gemma.py:149-194,282-329):
+ *   mode 1: q_proj | k_proj | v_proj (W = the three weights stacked) + apply_rotary_pos_emb on q and k, written
+ *           straight into the padded q buffer / static K and V caches (column segments, each with its own
+ *           destination and leading dimension; rows through the output row map);
+ *   mode 0: o_proj / down_proj + `x + y * gate` gated residual (same rounding order as kai0_gemm_bf16);
+ *   mode 2: gate_proj | up_proj (W = [gate ; up]) + GeGLU: h = bf16( bf16(gelu_tanh(bf16 g)) * bf16 u ).
+ * One block computes 64 rows x (16 + 16) weight rows that are `pair_stride` apart, so a RoPE pair (d, d + HD/2) or a
+ * GeGLU pair (gate_j, up_j) is combined in registers: pair_stride = HD/2 (mode 1), N/2 (mode 2), 16 (mode 0).
+ * K / split_k must be 512 or 1024.  split_k > 1 (mode 0 only, no gate / residual) cuts K over blocks so that the
+ * whole chip streams the weight: the kernel then writes the raw f32 partial products, `workspace` = f32
+ * [split_k][M][N] (kai0_skinny_workspace_bytes), and kai0_adarms_combine — the gated residual + adaRMS that follows
+ * o_proj / down_proj anyway — adds the splits in a fixed order (deterministic, no atomics).
+ * rope_cos / rope_sin: f32 [M][rope_half] tables from kai0_rope_table (bf16-rounded cos/sin of pos * inv_freq,
+ * exactly the values kai0_rope_inplace computes), indexed by the A row. */
+typedef struct kai0_skinny_seg {
+    void* dst;
+    int64_t ld;
+    int32_t n_begin, n_end; /* columns [n_begin, n_end) of the product go to dst[:, 0 : n_end - n_begin) */
+    int32_t rope, _pad;     /* 0 plain, 1 rotate (RoPE), 2 plain but stored transposed: dst is [batch][n_end-n_begin][ld]
+                             * and element (row, col) goes to dst[b][col][row'] with (b, row') from the output row map */
+} kai0_skinny_seg;
+
+typedef struct kai0_skinny_desc {
+    const void* A;
+    const void* W;
+    int64_t lda, ldw;
+    int32_t M, N, K;
+    int32_t pair_stride, mode, split_k;
+    int32_t a_rpb, c_rpb; /* row maps as in kai0_gemm_desc: row r -> (r / rpb) * bs + r % rpb + off; rpb = 0: identity */
+    int64_t a_bs, a_off, c_bs, c_off;
+    kai0_skinny_seg seg[3]; /* modes 0 and 2 use seg[0] only */
+    int32_t nseg, gate_rpb;
+    const void* gate; /* bf16 [M / gate_rpb][gate_ld] */
+    int64_t gate_ld;
+    const void* residual; /* bf16, addressed like the output */
+    int64_t ldr;
+    const float* rope_cos;
+    const float* rope_sin;
+    int32_t rope_half, _pad;
+    void* workspace;
+    int64_t workspace_bytes;
+} kai0_skinny_desc;
+
+int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stream);
+int kai0_skinny_desc_size(void);
+int64_t kai0_skinny_workspace_bytes(int M, int N, int split_k);
+/* Masked MQA attention of the denoise loop in one launch (modeling_gemma.py:224-259 eager_attention_forward with
+ * the prefix-LM mask of pi0_pytorch.py:52-81, queries = the suffix tokens, keys = the whole static cache):
+ *   Q, O : bf16 [batch][tokens][H][HD] (batch stride q_bs elements), query rows = tokens q0.., `rows` = n_tokens * H
+ *   K    : bf16 [batch][k_rows][k_ld] row-major keys (one KV head);  Vt : bf16 [batch][HD][vt_ld] TRANSPOSED values
+ *   allowed(b, token s, key j) = j < Sk && kcode[b][j] <= qcode[b][s]   (codes as in kai0_softmax_mask_fwd)
+ *   logits bf16(bf16(q.k) * scale) -> f32 softmax -> P bf16 -> O = bf16(P V) : the rounding points of
+ *   kai0_gemm_bf16 + kai0_softmax_mask_fwd + kai0_gemm_bf16.  HD = 256, Sk <= 1024, vt_ld >= round_up(Sk, 32). */
+int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void* O, const int32_t* qcode, const int32_t* kcode,
+                     int batch, int rows, int H, int HD, int Sk, int q0, int64_t q_bs, int64_t k_bs, int64_t k_ld,
+                     int k_rows, int64_t vt_bs, int64_t vt_ld, int64_t qcode_ld, int64_t kcode_ld, float scale,
+                     void* workspace, int64_t workspace_bytes, kai0_stream_t stream);
+/* bytes of the bf16 logits scratch kai0_attn_decode needs */
+int64_t kai0_attn_decode_workspace_bytes(int batch, int rows);
+/* batched strided transpose: dst[z][c][r] = src[z][r][c], r < R, c < C (all extents / strides multiples of 8) */
+int kai0_transpose_strided_bf16(const void* src, void* dst, int R, int C, int64_t src_ld, int64_t dst_ld, int batch,
+                                int64_t src_bs, int64_t dst_bs, kai0_stream_t stream);
+
+/* cos_out/sin_out[r][d] = bf16_round(cos/sin(inv_freq[d] * pos[r])) as f32, r < rows, d < half */
+int kai0_rope_table(const int32_t* pos, const float* inv_freq, float* cos_out, float* sin_out, int64_t rows, int half,
+                    kai0_stream_t stream);
+
 /* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C).
  * split_k > 1 slices the contraction over grid.z and combines with f32 atomics (summation order, hence the last
  * bits, then depend on scheduling) — used only for the long-contraction gradient reductions.
@@ -139,6 +209,12 @@ int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gate_out, fl
 int kai0_adarms_bwd(const void* dy, const void* dgate, const void* x, const float* mod, const float* rstd,
                     void* dx, float* dmod, const void* dres, int64_t rows, int rows_per_batch, int D,
                     kai0_stream_t stream);
+/* Denoise-loop companion of kai0_gemm_skinny_bf16: finishes a split-K o_proj / down_proj and runs the next adaRMS.
+ *   x = bf16( sum_s partials[s][row] ); x = bf16(x * gate_prev[b]) (if gate_prev); x = bf16(x + residual[row]) (if residual)
+ *   x_out = x;  y, gate_out = adaRMS(x, mod) exactly as kai0_adarms_fwd.   (gemma_pytorch.py:150-279 `_gated_residual`) */
+int kai0_adarms_combine(const float* partials, int splits, int64_t split_stride, const void* gate_prev,
+                        const void* residual, void* x_out, const float* mod, void* y, void* gate_out, int64_t rows,
+                        int rows_per_batch, int D, float eps, kai0_stream_t stream);
 /* LayerNorm over the last dim (modeling_siglip.py:439-441,756): bf16 x, bf16 w/b, f32 statistics. */
 int kai0_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
                        int64_t rows, int D, float eps, kai0_stream_t stream);

@@ -54,6 +54,27 @@ class AttnDesc(C.Structure):
     ]  # fmt: skip
 
 
+class SkinnySeg(C.Structure):
+    _fields_ = [("dst", c_p), ("ld", c_i64), ("n_begin", C.c_int32), ("n_end", C.c_int32), ("rope", C.c_int32),
+                ("_pad", C.c_int32)]  # fmt: skip
+
+
+class SkinnyDesc(C.Structure):
+    """Mirror of `kai0_skinny_desc` (include/kai0hip.h)."""
+
+    _fields_ = [
+        ("A", c_p), ("W", c_p), ("lda", c_i64), ("ldw", c_i64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("pair_stride", C.c_int32), ("mode", C.c_int32), ("split_k", C.c_int32),
+        ("a_rpb", C.c_int32), ("c_rpb", C.c_int32),
+        ("a_bs", c_i64), ("a_off", c_i64), ("c_bs", c_i64), ("c_off", c_i64),
+        ("seg", SkinnySeg * 3), ("nseg", C.c_int32), ("gate_rpb", C.c_int32),
+        ("gate", c_p), ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64),
+        ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("_pad", C.c_int32),
+        ("workspace", c_p), ("workspace_bytes", c_i64),
+    ]  # fmt: skip
+
+
 # name -> argtypes (every function returns int except where noted)
 _PROTOS: dict[str, list] = {
     "kai0_abi_version": [],
@@ -61,11 +82,18 @@ _PROTOS: dict[str, list] = {
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "kai0_attn_fwd": [C.POINTER(AttnDesc), c_p],
+    "kai0_gemm_skinny_bf16": [C.POINTER(SkinnyDesc), c_p],
+    "kai0_skinny_desc_size": [],
+    "kai0_attn_decode": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i64, c_i64,
+                         c_i64, c_i64, c_f, c_p, c_i64, c_p],
+    "kai0_transpose_strided_bf16": [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
+    "kai0_rope_table": [c_p, c_p, c_p, c_p, c_i64, c_i, c_p],
     "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
     "kai0_linear_rows_f32": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
     "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p],
     "kai0_adarms_fwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p],
+    "kai0_adarms_combine": [c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p],
     "kai0_adarms_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
     "kai0_layernorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
     "kai0_layernorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p],
@@ -101,7 +129,7 @@ _PROTOS: dict[str, list] = {
     "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
 }  # fmt: skip
 
-EXPORTED_SYMBOLS = ("kai0_last_error", *_PROTOS.keys())
+EXPORTED_SYMBOLS = ("kai0_last_error", "kai0_skinny_workspace_bytes", "kai0_attn_decode_workspace_bytes", *_PROTOS.keys())
 
 _lib = None
 
@@ -136,6 +164,14 @@ def load() -> C.CDLL:
     if lib.kai0_gemm_desc_size() != C.sizeof(GemmDesc):
         raise Kai0HipError(
             f"kai0_gemm_desc layout mismatch: C {lib.kai0_gemm_desc_size()} B vs ctypes {C.sizeof(GemmDesc)} B"
+        )
+    lib.kai0_attn_decode_workspace_bytes.restype = c_i64
+    lib.kai0_attn_decode_workspace_bytes.argtypes = [c_i, c_i]
+    lib.kai0_skinny_workspace_bytes.restype = c_i64
+    lib.kai0_skinny_workspace_bytes.argtypes = [c_i, c_i, c_i]
+    if lib.kai0_skinny_desc_size() != C.sizeof(SkinnyDesc):
+        raise Kai0HipError(
+            f"kai0_skinny_desc layout mismatch: C {lib.kai0_skinny_desc_size()} B vs ctypes {C.sizeof(SkinnyDesc)} B"
         )
     _lib = lib
     return lib

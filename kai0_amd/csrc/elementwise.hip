@@ -381,17 +381,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
 }
 
 // bf16 matrix transpose through LDS: src [R][C] -> dst [C][R]; 64x64 tiles, 16-B global accesses both ways.
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
+                                                        int64_t src_ld, int64_t dst_ld, int64_t src_bs, int64_t dst_bs) {
     __shared__ bf16_t tile[64][72];  // +8 pad: column reads hit different banks
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int t = threadIdx.x;
+    src += (int64_t)blockIdx.z * src_bs;
+    dst += (int64_t)blockIdx.z * dst_bs;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = p * 32 + (t >> 3), c8 = (t & 7) * 8;
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
-        if (r0 + r < R && c0 + c8 < C) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)(r0 + r) * C + c0 + c8);
+        if (r0 + r < R && c0 + c8 < C) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)(r0 + r) * src_ld + c0 + c8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[r][c8 + e] = v[e];
     }
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tile[r8 + e][c];
-            *reinterpret_cast<bf16x8*>(dst + (int64_t)(c0 + c) * R + r0 + r8) = v;
+            *reinterpret_cast<bf16x8*>(dst + (int64_t)(c0 + c) * dst_ld + r0 + r8) = v;
         }
     }
 }
@@ -625,8 +628,20 @@ KAI0_API int kai0_transpose_bf16(const void* src, void* dst, int R, int C, kai0_
     if (R <= 0 || C <= 0) return 0;
     dim3 grid((C + 63) / 64, (R + 63) / 64, 1);
     KAI0_REQUIRE(grid.y <= 65535, "kai0_transpose_bf16: R=%d too large", R);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_(stream), (const bf16_t*)src, (bf16_t*)dst, R, C);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_(stream), (const bf16_t*)src, (bf16_t*)dst, R, C, (int64_t)C,
+                       (int64_t)R, (int64_t)0, (int64_t)0);
     return kai0_check_launch("kai0_transpose_bf16");
+}
+KAI0_API int kai0_transpose_strided_bf16(const void* src, void* dst, int R, int C, int64_t src_ld, int64_t dst_ld, int batch,
+                                         int64_t src_bs, int64_t dst_bs, kai0_stream_t stream) {
+    KAI0_REQUIRE(R % 8 == 0 && C % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0 && src_bs % 8 == 0 && dst_bs % 8 == 0,
+                 "kai0_transpose_strided_bf16: dimensions and strides must be multiples of 8");
+    if (R <= 0 || C <= 0 || batch <= 0) return 0;
+    dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+    KAI0_REQUIRE(grid.y <= 65535 && batch <= 65535, "kai0_transpose_strided_bf16: R=%d / batch=%d too large", R, batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_(stream), (const bf16_t*)src, (bf16_t*)dst, R, C, src_ld,
+                       dst_ld, src_bs, dst_bs);
+    return kai0_check_launch("kai0_transpose_strided_bf16");
 }
 KAI0_API int kai0_patch_im2col(const float* img, float* cols, int n_img, int C, int HW, int P, kai0_stream_t stream) {
     KAI0_REQUIRE(HW % P == 0, "kai0_patch_im2col: image size %d not divisible by patch %d", HW, P);

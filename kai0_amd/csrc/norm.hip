@@ -86,6 +86,76 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
     }
 }
 
+// split-K combine + gated residual + adaRMS (inference denoise loop): one wave per row
+__global__ __launch_bounds__(256) void adarms_combine_kernel(const float* __restrict__ partials, int splits,
+                                                             int64_t split_stride, const bf16_t* __restrict__ gate_prev,
+                                                             const bf16_t* __restrict__ residual, bf16_t* __restrict__ x_out,
+                                                             const float* __restrict__ mod, bf16_t* __restrict__ y,
+                                                             bf16_t* __restrict__ gate_out, int64_t rows, int rpb, int D,
+                                                             float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const int64_t b = row / rpb;
+    float xv[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nchunk) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* pp = partials + row * D + ci * 8;
+            for (int s = 0; s < splits; ++s) {
+                float t[8];
+                loadf8(pp + (int64_t)s * split_stride, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = rbf(acc[e]);
+            if (gate_prev != nullptr) {
+                float g[8];
+                load8(gate_prev + b * D + ci * 8, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = rbf(acc[e] * g[e]);
+            }
+            if (residual != nullptr) {
+                float r[8];
+                load8(residual + row * D + ci * 8, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = rbf(acc[e] + r[e]);
+            }
+            store8(x_out + row * D + ci * 8, acc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[c][e] = acc[e];
+                ss += acc[e] * acc[e];
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    const float* mrow = mod + b * (int64_t)(3 * D);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nchunk) {
+            float o[8], sc[8], sh[8];
+            loadf8(mrow + ci * 8, sc);
+            loadf8(mrow + D + ci * 8, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] * rstd) * (1.0f + sc[e]) + sh[e];
+            store8(y + row * D + ci * 8, o);
+            if (gate_out != nullptr && (row % rpb) == 0) {
+                float gt[8];
+                loadf8(mrow + 2 * D + ci * 8, gt);
+                store8(gate_out + b * (int64_t)D + ci * 8, gt);
+            }
+        }
+    }
+}
+
 // plain RMSNorm backward: dx and per-wave dw partials [gridDim.x*4][D]
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ rstd_in,
@@ -420,6 +490,18 @@ KAI0_API int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gat
                        (const bf16_t*)x, (const float*)nullptr, mod, (bf16_t*)y, (bf16_t*)gate_out, rstd, rows,
                        rows_per_batch, D, eps);
     return kai0_check_launch("kai0_adarms_fwd");
+}
+
+KAI0_API int kai0_adarms_combine(const float* partials, int splits, int64_t split_stride, const void* gate_prev,
+                                 const void* residual, void* x_out, const float* mod, void* y, void* gate_out,
+                                 int64_t rows, int rows_per_batch, int D, float eps, kai0_stream_t stream) {
+    CHECK_D("kai0_adarms_combine", D);
+    KAI0_REQUIRE(partials && splits >= 1 && x_out && mod && y && rows_per_batch > 0, "kai0_adarms_combine: bad arguments");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(adarms_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, partials,
+                       splits, split_stride, (const bf16_t*)gate_prev, (const bf16_t*)residual, (bf16_t*)x_out, mod,
+                       (bf16_t*)y, (bf16_t*)gate_out, rows, rows_per_batch, D, eps);
+    return kai0_check_launch("kai0_adarms_combine");
 }
 
 KAI0_API int kai0_adarms_bwd(const void* dy, const void* dgate, const void* x, const float* mod, const float* rstd,

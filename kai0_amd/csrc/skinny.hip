@@ -1,0 +1,336 @@
+// skinny.hip — few-row (M <= 64 per tile) weight-streaming GEMM for the denoise loop of action-chunk inference:
+//   C[M, N] = A[M, K] @ W[N, K]^T with the surrounding element-wise work fused into the epilogue.
+//
+// At B = 1 the action expert multiplies 50 token rows by 0.6 GB of weights ten times per chunk: the job is to stream
+// W once at HBM speed and to launch as few kernels as possible, not to feed MFMA.  gfx950 design:
+//   * one block = 64 rows x 32 output-weight rows (two 16-row groups `pair_stride` apart, so the RoPE partner column
+//     d + 128 of a head, or the `up` column of a GeGLU pair, lands in the SAME lane and register as its mate);
+//   * grid = tiles x split_k (x row tiles): the contraction is cut over blocks until the chip is full; inside the
+//     block each of the 4 waves owns a quarter of the block's K range (1 or 2 chunks of 128);
+//   * operands never touch LDS: every lane reads its MFMA fragment straight from global as 4 x 16 B = 64 contiguous
+//     bytes per row (the contraction index inside a 128-chunk is permuted identically for A and W, which a dot
+//     product does not care about), all loads of a chunk in flight before the first MFMA;
+//   * wave partials meet in LDS; with split_k > 1 the block writes its raw f32 partial product [split][M][N] and the
+//     consumer kernel (kai0_adarms_combine: gated residual + adaRMS, needed anyway) adds the splits in a fixed order.
+//     (An in-kernel "last block reduces" scheme was measured at 24-41 us per launch: the agent-scope fences it needs
+//     write back / invalidate the whole L2.  The kernel boundary gives the same visibility for free.)
+//   * epilogues (rounding points identical to the separate kernels they replace, see kai0hip.h):
+//       plain  : bf16 -> (* gate) -> (+ residual)
+//       rope   : up to 3 column segments (q | k | v) with their own destination / leading dimension; rotated with
+//                precomputed bf16-rounded cos/sin tables
+//       geglu  : h = bf16( bf16(gelu_tanh(g)) * u ), W = [gate ; up]
+#include "common.h"
+#include "../../include/kai0hip.h"
+
+namespace {
+
+struct SkRowMap {
+    int32_t rpb;
+    int64_t bs, off;
+    __device__ __forceinline__ int64_t operator()(int r) const {
+        if (rpb == 0) return r;
+        const int q = r / rpb;
+        return (int64_t)q * bs + (r - q * rpb) + off;
+    }
+};
+
+struct SkSeg {
+    bf16_t* dst;
+    int64_t ld;
+    int32_t n_begin, n_end, rope;
+};
+
+struct SkinnyArgs {
+    const bf16_t* A;
+    const bf16_t* W;
+    int64_t lda, ldw;
+    int M, N, K;
+    int pair_stride, mode, split_k, k_blk;
+    SkRowMap amap, cmap;
+    SkSeg seg[3];
+    int nseg;
+    const bf16_t* gate;
+    int gate_rpb;
+    int64_t gate_ld;
+    const bf16_t* residual;
+    int64_t ldr;
+    const float* rope_cos;
+    const float* rope_sin;
+    int rope_half;
+    float* ws;
+};
+
+constexpr int TM = 64, TN = 32;
+constexpr int RED_LD = TN + 1;  // f32 row stride of a wave's partial tile in LDS (odd: conflict-free column writes)
+
+template <int NC>
+__global__ __launch_bounds__(256, 1) void skinny_kernel(const SkinnyArgs p) {
+    __shared__ float red[4][TM][RED_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, ks = blockIdx.y, mt_blk = blockIdx.z;
+    const int per = p.pair_stride >> 4;
+    const int n_sub0 = (tile / per) * (2 * p.pair_stride) + (tile % per) * 16;
+    const int n_sub1 = n_sub0 + p.pair_stride;
+    const int m0 = mt_blk * TM;
+    const int kw0 = ks * p.k_blk + wave * (p.k_blk >> 2);
+
+    // ---- all fragment loads of this wave's K slice, then the MFMAs --------------------------------
+    const bf16_t* w0 = p.W + (int64_t)(n_sub0 + i) * p.ldw + kw0 + 32 * g;
+    const bf16_t* w1 = p.W + (int64_t)(n_sub1 + i) * p.ldw + kw0 + 32 * g;
+    const bf16_t* arow[4];
+    bool aok[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = m0 + mt * 16 + i;
+        aok[mt] = r < p.M;
+        arow[mt] = p.A + p.amap(aok[mt] ? r : 0) * p.lda + kw0 + 32 * g;
+    }
+    bf16x8 wf[NC][2][4], af[NC][4][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wf[c][0][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w0 + c * 128 + 8 * j));
+            wf[c][1][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + c * 128 + 8 * j));
+        }
+    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                af[c][mt][j] = aok[mt] ? *reinterpret_cast<const bf16x8*>(arow[mt] + c * 128 + 8 * j) : zero8;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c][mt][j], wf[c][0][j], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c][mt][j], wf[c][1][j], acc[mt][1], 0, 0, 0);
+            }
+
+    // ---- wave partials -> LDS -> per-thread 4+4 outputs --------------------------------------------
+    // C layout of a 16x16 MFMA tile: col = lane & 15 (W row), row = 4*(lane >> 4) + reg (A row)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][mt * 16 + 4 * g + r][s * 16 + i] = acc[mt][s][r];
+    __syncthreads();
+    const int row = tid >> 2, q = tid & 3;
+    float v0[4], v1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v0[e] = (red[0][row][4 * q + e] + red[1][row][4 * q + e]) + (red[2][row][4 * q + e] + red[3][row][4 * q + e]);
+        v1[e] = (red[0][row][16 + 4 * q + e] + red[1][row][16 + 4 * q + e]) +
+                (red[2][row][16 + 4 * q + e] + red[3][row][16 + 4 * q + e]);
+    }
+
+    // ---- split-K: raw f32 partial products [split][M][N]; the consumer (kai0_adarms_combine) adds them in order ----
+    if (p.split_k > 1) {
+        const int mrow_p = m0 + row;
+        if (mrow_p < p.M) {
+            float* dstp = p.ws + ((int64_t)ks * p.M + mrow_p) * p.N;
+            *reinterpret_cast<f32x4*>(dstp + n_sub0 + 4 * q) = f32x4{v0[0], v0[1], v0[2], v0[3]};
+            *reinterpret_cast<f32x4*>(dstp + n_sub1 + 4 * q) = f32x4{v1[0], v1[1], v1[2], v1[3]};
+        }
+        return;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------
+    const int mrow = m0 + row;
+    if (mrow >= p.M) return;
+    const int64_t orow = p.cmap(mrow);
+    const int n0 = n_sub0 + 4 * q, n1 = n_sub1 + 4 * q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v0[e] = rbf(v0[e]);
+        v1[e] = rbf(v1[e]);
+    }
+    if (p.mode == 2) {  // GeGLU: v0 = gate pre-activation, v1 = up
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(gelu_tanh_f(v0[e])) * v1[e]);
+        *reinterpret_cast<bf16x4*>(p.seg[0].dst + orow * p.seg[0].ld + n0) = o;
+        return;
+    }
+    if (p.mode == 1) {  // column segments, optional rotation
+        int si = 0;
+        if (p.nseg > 1 && n0 >= p.seg[1].n_begin) si = 1;
+        if (p.nseg > 2 && n0 >= p.seg[2].n_begin) si = 2;
+        const SkSeg sg = p.seg[si];
+        const int c0 = n0 - sg.n_begin;
+        bf16x4 o1, o2;
+        if (sg.rope == 1) {
+            const int d = c0 % (2 * p.rope_half);  // index inside the head, < rope_half by construction
+            const float* ct = p.rope_cos + (int64_t)mrow * p.rope_half + d;
+            const float* st = p.rope_sin + (int64_t)mrow * p.rope_half + d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = ct[e], s = st[e];
+                o1[e] = f2bf(rbf(v0[e] * c) + rbf(-v1[e] * s));
+                o2[e] = f2bf(rbf(v1[e] * c) + rbf(v0[e] * s));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o1[e] = f2bf(v0[e]);
+                o2[e] = f2bf(v1[e]);
+            }
+        }
+        if (sg.rope == 2) {
+            // transposed destination [batch][cols][ld] (value cache of kai0_attn_decode): element (row, col) -> dst[col][row]
+            const int bq = p.cmap.rpb ? mrow / p.cmap.rpb : 0;
+            const int64_t srow = p.cmap.rpb ? (int64_t)(mrow - bq * p.cmap.rpb) + p.cmap.off : (int64_t)mrow;
+            bf16_t* dp = sg.dst + (int64_t)bq * (sg.n_end - sg.n_begin) * sg.ld + (int64_t)c0 * sg.ld + srow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dp[(int64_t)e * sg.ld] = o1[e];
+                dp[(int64_t)(e + p.pair_stride) * sg.ld] = o2[e];
+            }
+            return;
+        }
+        bf16_t* dp = sg.dst + orow * sg.ld + c0;
+        *reinterpret_cast<bf16x4*>(dp) = o1;
+        *reinterpret_cast<bf16x4*>(dp + p.pair_stride) = o2;
+        return;
+    }
+    if (p.gate != nullptr) {
+        const bf16_t* gp = p.gate + (int64_t)(mrow / p.gate_rpb) * p.gate_ld;
+        const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(gp + n0);
+        const bf16x4 g1 = *reinterpret_cast<const bf16x4*>(gp + n1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = rbf(v0[e] * bf2f(g0[e]));
+            v1[e] = rbf(v1[e] * bf2f(g1[e]));
+        }
+    }
+    if (p.residual != nullptr) {
+        const bf16_t* rp = p.residual + orow * p.ldr;
+        const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(rp + n0);
+        const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(rp + n1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = rbf(v0[e] + bf2f(r0[e]));
+            v1[e] = rbf(v1[e] + bf2f(r1[e]));
+        }
+    }
+    bf16x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o1[e] = f2bf(v0[e]);
+        o2[e] = f2bf(v1[e]);
+    }
+    bf16_t* dp = p.seg[0].dst + orow * p.seg[0].ld;
+    *reinterpret_cast<bf16x4*>(dp + n0) = o1;
+    *reinterpret_cast<bf16x4*>(dp + n1) = o2;
+}
+
+__global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restrict__ pos, const float* __restrict__ inv_freq,
+                                                         float* __restrict__ cos_out, float* __restrict__ sin_out,
+                                                         int64_t n, int half) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int64_t r = t / half;
+    const int d = (int)(t - r * half);
+    const float ang = inv_freq[d] * (float)pos[r];
+    cos_out[t] = rbf(cosf(ang));
+    sin_out[t] = rbf(sinf(ang));
+}
+
+}  // namespace
+
+KAI0_API int kai0_skinny_desc_size(void) { return (int)sizeof(kai0_skinny_desc); }
+
+KAI0_API int64_t kai0_skinny_workspace_bytes(int M, int N, int split_k) {
+    return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
+}
+
+KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stream) {
+    KAI0_REQUIRE(d != nullptr && d->A && d->W, "kai0_gemm_skinny_bf16: null operand");
+    KAI0_REQUIRE(d->M >= 1 && d->N >= 32 && d->N % 32 == 0, "kai0_gemm_skinny_bf16: M=%d N=%d unsupported", d->M, d->N);
+    const int S = d->split_k < 1 ? 1 : d->split_k;
+    KAI0_REQUIRE(d->K % S == 0 && ((d->K / S) == 512 || (d->K / S) == 1024),
+                 "kai0_gemm_skinny_bf16: K=%d split_k=%d: K/split_k must be 512 or 1024", d->K, S);
+    KAI0_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && ((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0,
+                 "kai0_gemm_skinny_bf16: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
+    const int ps = d->pair_stride;
+    KAI0_REQUIRE(ps >= 16 && ps % 16 == 0 && d->N % (2 * ps) == 0, "kai0_gemm_skinny_bf16: pair_stride=%d does not tile N=%d",
+                 ps, d->N);
+    KAI0_REQUIRE(d->mode >= 0 && d->mode <= 2, "kai0_gemm_skinny_bf16: mode=%d", d->mode);
+    KAI0_REQUIRE(S > 1 || (d->nseg >= 1 && d->nseg <= 3 && d->seg[0].dst), "kai0_gemm_skinny_bf16: nseg=%d", d->nseg);
+    SkinnyArgs a{};
+    a.A = (const bf16_t*)d->A;
+    a.W = (const bf16_t*)d->W;
+    a.lda = d->lda;
+    a.ldw = d->ldw;
+    a.M = d->M;
+    a.N = d->N;
+    a.K = d->K;
+    a.pair_stride = ps;
+    a.mode = d->mode;
+    a.split_k = S;
+    a.k_blk = d->K / S;
+    a.amap = SkRowMap{d->a_rpb, d->a_bs, d->a_off};
+    a.cmap = SkRowMap{d->c_rpb, d->c_bs, d->c_off};
+    a.nseg = S > 1 ? 0 : d->nseg;
+    for (int s = 0; s < a.nseg; ++s) {
+        a.seg[s] = SkSeg{(bf16_t*)d->seg[s].dst, d->seg[s].ld, d->seg[s].n_begin, d->seg[s].n_end, d->seg[s].rope};
+        KAI0_REQUIRE(d->seg[s].dst && (d->seg[s].ld % 4 == 0 || d->seg[s].rope == 2), "kai0_gemm_skinny_bf16: segment %d destination", s);
+    }
+    if (d->mode == 1) {
+        int expect = 0;
+        for (int s = 0; s < d->nseg; ++s) {
+            KAI0_REQUIRE(d->seg[s].n_begin == expect && d->seg[s].n_end > expect && (d->seg[s].n_end - expect) % (2 * ps) == 0,
+                         "kai0_gemm_skinny_bf16: segments must tile [0, N) in multiples of 2*pair_stride");
+            expect = d->seg[s].n_end;
+            if (d->seg[s].rope == 1)
+                KAI0_REQUIRE(d->rope_cos && d->rope_sin && d->rope_half == ps,
+                             "kai0_gemm_skinny_bf16: rope needs cos/sin tables with rope_half == pair_stride");
+        }
+        KAI0_REQUIRE(expect == d->N, "kai0_gemm_skinny_bf16: segments cover %d of N=%d columns", expect, d->N);
+    }
+    if (d->mode == 2) KAI0_REQUIRE(ps * 2 == d->N, "kai0_gemm_skinny_bf16: geglu needs W = [gate; up], pair_stride = N/2");
+    a.gate = (const bf16_t*)d->gate;
+    a.gate_rpb = d->gate_rpb > 0 ? d->gate_rpb : 1;
+    a.gate_ld = d->gate_ld;
+    a.residual = (const bf16_t*)d->residual;
+    a.ldr = d->ldr;
+    a.rope_cos = d->rope_cos;
+    a.rope_sin = d->rope_sin;
+    a.rope_half = d->rope_half > 0 ? d->rope_half : ps;
+    const int tiles = d->N / TN, mtiles = (d->M + TM - 1) / TM;
+    if (S > 1) {
+        const int64_t need = (int64_t)S * d->M * d->N * 4;
+        KAI0_REQUIRE(d->mode == 0 && d->gate == nullptr && d->residual == nullptr,
+                     "kai0_gemm_skinny_bf16: split_k > 1 produces raw partial products (mode 0, no gate / residual)");
+        KAI0_REQUIRE(d->workspace && d->workspace_bytes >= need && ((uintptr_t)d->workspace % 16) == 0,
+                     "kai0_gemm_skinny_bf16: split_k=%d needs %lld workspace bytes", S, (long long)need);
+        a.ws = (float*)d->workspace;
+    }
+    const dim3 grid(tiles, S, mtiles);
+    if (a.k_blk == 512)
+        hipLaunchKernelGGL(skinny_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(skinny_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return kai0_check_launch("kai0_gemm_skinny_bf16");
+}
+
+KAI0_API int kai0_rope_table(const int32_t* pos, const float* inv_freq, float* cos_out, float* sin_out, int64_t rows,
+                             int half, kai0_stream_t stream) {
+    const int64_t n = rows * half;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, inv_freq,
+                       cos_out, sin_out, n, half);
+    return kai0_check_launch("kai0_rope_table");
+}

@@ -51,7 +51,7 @@ class InferenceEngine:
         self.Hs = model.config.action_horizon
         self.A = model.config.action_dim
         self.S = self.P + self.Hs
-        self.S_ld = round_up(self.S, 8)
+        self.S_ld = round_up(self.S, 32)  # padded rows: 32-key groups of the decode attention never leave the buffers
         cfg = pe.vlm_cfg
         self.H, self.HD = cfg.num_heads, cfg.head_dim
         self.Dp, self.De = cfg.width, pe.exp_cfg.width
@@ -60,10 +60,19 @@ class InferenceEngine:
         self.dev = dev
         B, S_ld, H, HD = self.B, self.S_ld, self.H, self.HD
         self.k_cache = [torch.zeros((B, S_ld, HD), dtype=BF16, device=dev) for _ in range(self.L)]
-        self.v_cache = [torch.zeros((B, S_ld, HD), dtype=BF16, device=dev) for _ in range(self.L)]
+        self.v_all = torch.zeros((self.L, B, S_ld, HD), dtype=BF16, device=dev)
+        self.v_cache = [self.v_all[l] for l in range(self.L)]
         self.q_buf = torch.zeros((B, S_ld, H * HD), dtype=BF16, device=dev)
         self.att_buf = torch.zeros((B, S_ld, H * HD), dtype=BF16, device=dev)
         self.use_graph = os.environ.get("KAI0_INFER_GRAPH", "1") != "0"
+        # few denoise rows (B * horizon <= 128): weight-streaming GEMMs with fused RoPE / GeGLU / gated-residual epilogues
+        ecfg = pe.exp_cfg
+        self.skinny = (B * self.Hs <= 128 and os.environ.get("KAI0_INFER_SKINNY", "1") != "0"
+                       and all(k % 512 == 0 for k in (ecfg.width, ecfg.mlp_dim, H * HD)) and HD % 32 == 0
+                       and ecfg.width % 32 == 0 and ecfg.mlp_dim % 16 == 0)  # fmt: skip
+        self._weights_tag = self._fingerprint()
+        if self.skinny:
+            self._build_skinny()
         self._times_dev = {}
         self._graph = None
         self._graph_steps = None
@@ -71,7 +80,32 @@ class InferenceEngine:
         self._static_out = None
 
     def compatible(self, batch, n_lang, n_cam):
-        return (batch, n_lang, n_cam) == (self.B, self.T, self.ncam)
+        return (batch, n_lang, n_cam) == (self.B, self.T, self.ncam) and self._weights_tag == self._fingerprint()
+
+    def _fingerprint(self):
+        """Identity of the weights this engine (its stacked copies and its captured graph) was built from."""
+        ex = self.pe.gemma_expert.model
+        srcs = [w for l in ex.layers for w in (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
+                                                l.mlp.gate_proj.weight, l.mlp.up_proj.weight)]  # fmt: skip
+        return tuple((p.data_ptr(), p._version) for p in srcs)
+
+    def _build_skinny(self):
+        ex = self.pe.gemma_expert.model
+        B, Hs, H, HD, De, dev = self.B, self.Hs, self.H, self.HD, self.De, self.dev
+        M = B * Hs
+        self.F = ex.layers[0].mlp.gate_proj.weight.shape[0]
+        # stacked copies (0.5 GB): q|k|v and gate|up become one weight stream and one launch each
+        self.w_qkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
+                      for l in ex.layers]  # fmt: skip
+        self.w_gu = [torch.cat([l.mlp.gate_proj.weight, l.mlp.up_proj.weight], 0).contiguous() for l in ex.layers]
+        # o_proj / down_proj: split-K partial products, finished by adarms_combine
+        self.S_o, self.S_d = ops.skinny_split_k(De, H * HD), ops.skinny_split_k(De, self.F)
+        self.ws_o = ops.skinny_workspace(M, De, self.S_o, dev)
+        self.ws_d = ops.skinny_workspace(M, De, self.S_d, dev)
+        # one-launch decode attention: needs the value cache transposed ([HD][keys])
+        self.decode_attn = HD == 256 and self.S <= 1024 and self.P % 8 == 0
+        if self.decode_attn:
+            self.vt_all = torch.zeros((self.L, B, HD, self.S_ld), dtype=BF16, device=dev)
 
     # ---------------------------------------------------------------------------------------------- attention
     def _attend(self, l: int, q0: int, Sq: int, Sk: int, qcode, kcode):
@@ -168,6 +202,40 @@ class InferenceEngine:
         mf = ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
         return mods, mf
 
+    def _expert_stack_skinny(self, xs, mods, mf, rows):
+        """All expert layers of one denoise step, 8 launches per layer: q|k|v+RoPE, logits, softmax, P V (+reduce),
+        o_proj partials, [sum + gated residual + adaRMS], gate|up+GeGLU, down_proj partials, [sum + gated residual +
+        the NEXT layer's (or the final) adaRMS]."""
+        B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
+        M, dev = B * Hs, self.dev
+        cos, sin = self._rope_cs
+        layers = self.pe.gemma_expert.model.layers
+        NQ = H * HD
+        hs, gate1 = ops.adarms(xs, mods[0][0][rows], Hs, layers[0].input_layernorm.eps)
+        for l, layer in enumerate(layers):
+            ops.skinny_gemm(hs, self.w_qkv[l], M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2,
+                            segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
+                                  (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2) if self.decode_attn
+                                  else (self.v_cache[l], HD, NQ + HD, NQ + 2 * HD, 0)],
+                            c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2)  # fmt: skip
+            if self.decode_attn:
+                ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
+                                rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
+                                vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
+            else:
+                self._attend(l, P, Hs, P + Hs, self.qcode, self.kcode)
+            ops.skinny_gemm(self.att_buf, layer.self_attn.o_proj.weight, M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=self.S_o,
+                            workspace=self.ws_o, a_map=(Hs, S_ld, P))  # fmt: skip
+            x1, hs, gate2 = ops.adarms_combine(self.ws_o, gate1, xs, mods[l][1][rows], Hs, layer.post_attention_layernorm.eps)
+            h = torch.empty((M, F), dtype=BF16, device=dev)
+            ops.skinny_gemm(hs, self.w_gu[l], M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, segs=[(h, F, 0, F, 0)])
+            ops.skinny_gemm(h, layer.mlp.down_proj.weight, M=M, N=De, K=F, lda=F, ldw=F, split_k=self.S_d, workspace=self.ws_d)
+            last = l + 1 == len(layers)
+            nmod = mf[rows] if last else mods[l + 1][0][rows]
+            neps = self.pe.gemma_expert.model.norm.eps if last else layers[l + 1].input_layernorm.eps
+            xs, hs, gate1 = ops.adarms_combine(self.ws_d, gate2, x1, nmod, Hs, neps)
+        return hs  # = final adaRMS norm of the last residual stream
+
     def _denoise_step(self, x_t, step: int, mods, mf):
         model, pe = self.model, self.pe
         B, P, Hs, De = self.B, self.P, self.Hs, self.De
@@ -177,6 +245,10 @@ class InferenceEngine:
         a = ops.linear_f32(x_t.view(B * Hs, self.A), model.action_in_proj.weight, model.action_in_proj.bias)
         xs = ops.cast(a, BF16)
         rows = slice(step * B, (step + 1) * B)
+        if self.skinny:
+            out = self._expert_stack_skinny(xs, mods, mf, rows)
+            v = ops.linear_f32(ops.cast(out, F32), model.action_out_proj.weight, model.action_out_proj.bias)
+            return v.view(B, Hs, self.A)
         for l, layer in enumerate(ex.layers):
             m1, m2 = mods[l][0][rows], mods[l][1][rows]
             hs, gate1 = ops.adarms(xs, m1, Hs, layer.input_layernorm.eps)
@@ -204,6 +276,11 @@ class InferenceEngine:
             self._times_dev[tuple(times)] = torch.tensor(times, dtype=F32).repeat_interleave(self.B).to(self.dev)
         self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
         mods, mf = self._modulations(times)
+        if self.skinny:
+            self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
+            if self.decode_attn:  # prefix value rows of every layer -> transposed cache, one launch
+                ops.transpose_strided(self.v_all, self.vt_all, R=self.P, C=self.HD, src_ld=self.HD, dst_ld=self.S_ld,
+                                      batch=self.L * self.B, src_bs=self.S_ld * self.HD, dst_bs=self.HD * self.S_ld)
         x_t = noise.clone().contiguous()
         for step in range(len(times)):
             v_t = self._denoise_step(x_t, step, mods, mf)

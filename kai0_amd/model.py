@@ -394,6 +394,24 @@ class PI0Pytorch(nn.Module):
         self._engine = None
 
     # ---- reference API ------------------------------------------------------------------------------------
+    # The inference engine holds stacked weight copies and a captured hipGraph: anything that can change or move the
+    # parameters drops it (it is rebuilt on the next sample_actions call).
+    def invalidate_inference_engine(self):
+        self._engine = None
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._engine = None
+        return super().train(mode)
+
+    def _apply(self, fn, recurse=True):
+        self._engine = None
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
+
     def gradient_checkpointing_enable(self):
         """pi0_pytorch.py:126-133. Activations fit in 288 GB HBM, so this is optional here; when enabled each
         layer is rematerialised in backward exactly like the reference's per-layer checkpoint."""

@@ -104,6 +104,98 @@ def gemm(
     return out
 
 
+def skinny_split_k(N: int, K: int) -> int:
+    """Split of the contraction for a mode-0 kai0_gemm_skinny_bf16 whose consumer is kai0_adarms_combine: enough blocks
+    to occupy the chip (N/32 tiles x split >= ~190), K / split in {1024, 512}."""
+    if K % 512:
+        raise _lib.Kai0HipError(f"skinny gemm: K={K} must be a multiple of 512")
+    tiles = N // 32
+    if K % 1024 == 0 and tiles * (K // 1024) >= 190:
+        return K // 1024
+    return K // 512
+
+
+def skinny_workspace(M: int, N: int, split_k: int, device) -> torch.Tensor:
+    """f32 [split_k][M][N] partial-product buffer of a split-K skinny GEMM."""
+    return torch.empty((max(split_k, 1), M, N), dtype=F32, device=device)
+
+
+def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int = 0, pair_stride: int = 16, segs=None,
+                split_k: int = 1, workspace=None, a_map=None, c_map=None, gate=None, gate_rpb: int = 0, gate_ld: int = 0,
+                residual=None, ldr: int = 0, rope_cos=None, rope_sin=None, rope_half: int = 0):  # fmt: skip
+    """kai0_gemm_skinny_bf16.  segs = [(dst, ld, n_begin, n_end, rope)]."""
+    for t in (A, W):
+        if not t.is_cuda or t.dtype != BF16:
+            raise _lib.Kai0HipError("skinny_gemm: expected bf16 CUDA (HIP) tensors; the product path has no CPU fallback")
+    d = _lib.SkinnyDesc()
+    d.A, d.W, d.lda, d.ldw = A.data_ptr(), W.data_ptr(), lda, ldw
+    d.M, d.N, d.K = M, N, K
+    d.pair_stride, d.mode, d.split_k = pair_stride, mode, split_k
+    if a_map:
+        d.a_rpb, d.a_bs, d.a_off = a_map
+    if c_map:
+        d.c_rpb, d.c_bs, d.c_off = c_map
+    d.nseg = len(segs or ())
+    for i, (dst, ld, nb, ne, rope) in enumerate(segs or ()):
+        if not dst.is_cuda or dst.dtype != BF16:
+            raise _lib.Kai0HipError("skinny_gemm: destinations must be bf16 CUDA (HIP) tensors")
+        d.seg[i].dst, d.seg[i].ld, d.seg[i].n_begin, d.seg[i].n_end, d.seg[i].rope = dst.data_ptr(), ld, nb, ne, int(rope)
+    if gate is not None:
+        d.gate, d.gate_rpb, d.gate_ld = gate.data_ptr(), gate_rpb, gate_ld
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), ldr
+    if rope_cos is not None:
+        d.rope_cos, d.rope_sin, d.rope_half = rope_cos.data_ptr(), rope_sin.data_ptr(), rope_half
+    if split_k > 1:
+        if workspace is None or workspace.dtype != F32:
+            raise _lib.Kai0HipError("skinny_gemm: split_k > 1 writes f32 partial products into `workspace` (skinny_workspace)")
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * 4
+    _lib.call("kai0_gemm_skinny_bf16", C.byref(d), _stream())
+
+
+def adarms_combine(partials, gate_prev, residual, mod, rows_per_batch: int, eps: float = 1e-6):
+    """kai0_adarms_combine: partials f32 [S][rows][D] -> (x, y, gate) with x = gated residual of the summed product,
+    (y, gate) = adaRMS(x, mod)."""
+    S, rows, D = partials.shape
+    Bn = rows // rows_per_batch
+    dev = partials.device
+    x = torch.empty((rows, D), dtype=BF16, device=dev)
+    y = torch.empty((rows, D), dtype=BF16, device=dev)
+    gate = torch.empty((Bn, D), dtype=BF16, device=dev)
+    _lib.call("kai0_adarms_combine", partials.data_ptr(), S, rows * D, _p(gate_prev), _p(residual), x.data_ptr(),
+              mod.data_ptr(), y.data_ptr(), gate.data_ptr(), rows, rows_per_batch, D, eps, _stream())  # fmt: skip
+    return x, y, gate
+
+
+def attn_decode(Q, K, Vt, O, qcode, kcode, *, batch, rows, H, HD, Sk, q0, q_bs, k_bs, k_ld, k_rows, vt_bs, vt_ld, scale):
+    """kai0_attn_decode (masked MQA of the denoise loop in two launches; Vt is the transposed value cache)."""
+    for t in (Q, K, Vt, O):
+        if not t.is_cuda or t.dtype != BF16:
+            raise _lib.Kai0HipError("attn_decode: expected bf16 CUDA (HIP) tensors; the product path has no CPU fallback")
+    ws = _workspace(int(_lib.load().kai0_attn_decode_workspace_bytes(batch, rows)), Q.device)
+    _lib.call("kai0_attn_decode", Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), O.data_ptr(), _p(qcode), _p(kcode), batch, rows,
+              H, HD, Sk, q0, q_bs, k_bs, k_ld, k_rows, vt_bs, vt_ld, qcode.stride(0) if qcode is not None else 0,
+              kcode.stride(0) if kcode is not None else 0, scale, ws.data_ptr(), ws.numel(), _stream())  # fmt: skip
+
+
+def transpose_strided(src, dst, *, R, C, src_ld, dst_ld, batch=1, src_bs=0, dst_bs=0):
+    """dst[z][c][r] = src[z][r][c] (kai0_transpose_strided_bf16)."""
+    _lib.call("kai0_transpose_strided_bf16", src.data_ptr(), dst.data_ptr(), R, C, src_ld, dst_ld, batch, src_bs, dst_bs,
+              _stream())  # fmt: skip
+
+
+def rope_table(pos, inv_freq):
+    """-> (cos, sin) f32 [rows, HD/2], bf16-rounded values, rows = pos.numel() (pos int32)."""
+    pos = pos.contiguous()
+    if pos.dtype != torch.int32:
+        raise TypeError("rope_table: pos must be int32")
+    rows, half = pos.numel(), inv_freq.numel()
+    cos = torch.empty((rows, half), dtype=F32, device=pos.device)
+    sin = torch.empty((rows, half), dtype=F32, device=pos.device)
+    _lib.call("kai0_rope_table", pos.data_ptr(), inv_freq.data_ptr(), cos.data_ptr(), sin.data_ptr(), rows, half, _stream())
+    return cos, sin
+
+
 _WS: dict = {}
 
 

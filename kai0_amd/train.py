@@ -40,6 +40,8 @@ class Trainer:
     def train_step(self, observation, actions, noise=None, time=None) -> torch.Tensor:
         """Returns the (local) mean loss as a 0-d device tensor — no host sync inside the step."""
         lr = self.lr()
+        if getattr(self.model, "_engine", None) is not None:
+            self.model.invalidate_inference_engine()  # the step below rewrites the weights through raw pointers
         losses = self.model(observation, actions, noise=noise, time=time)
         loss = losses.mean()
         loss.backward()

@@ -649,3 +649,170 @@ def test_adamw_and_clip(ops):
     for p, r, m in zip(params, ref, opt.master_params()):
         assert rel_err(m, r) < 1e-5
         assert torch.equal(p.detach(), m.to(p.dtype))
+
+
+# ------------------------------------------------------------------------------------ skinny (denoise) GEMM
+@pytest.mark.parametrize("M,K,N", [(50, 1024, 1024), (100, 1024, 512), (7, 512, 64)])
+def test_skinny_plain_gate_residual(ops, M, K, N):
+    """mode 0 without split: row-mapped A, gate * y + residual epilogue; same rounding points as kai0_gemm_bf16."""
+    rpb, S_ld, row0 = (50 if M % 50 == 0 else M), 72, 11
+    nb = M // rpb
+    a_buf = rnd(nb * S_ld, K, seed=1)
+    w = rnd(N, K, seed=2, scale=0.05)
+    gate = rnd(nb, N, seed=3)
+    res = rnd(M, N, seed=4)
+    ref = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a_buf, w, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_map=(rpb, S_ld, row0), gate=gate, gate_rpb=rpb, gate_ld=N,
+             residual=res, ldr=N)
+    out = torch.zeros(M, N, dtype=BF16, device=dev())
+    ops.skinny_gemm(a_buf, w, M=M, N=N, K=K, lda=K, ldw=K, segs=[(out, N, 0, N, 0)], a_map=(rpb, S_ld, row0), gate=gate,
+                    gate_rpb=rpb, gate_ld=N, residual=res, ldr=N)
+    rows = torch.cat([torch.arange(rpb) + b * S_ld + row0 for b in range(nb)]).to(dev())
+    y = (a_buf[rows].float() @ w.float().t()).to(BF16).float()
+    y = (y * gate.float().repeat_interleave(rpb, 0)).to(BF16).float()
+    y = (y + res.float()).to(BF16)
+    assert_close_bf16(out, y.float(), what="skinny plain", tol=1e-2)
+    assert rel_err(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,N,split", [(50, 2048, 1024, 4), (50, 4096, 1024, 8), (100, 4096, 1024, 4)])
+def test_skinny_splitk_partials_and_adarms_combine(ops, M, K, N, split):
+    """o_proj / down_proj form: split-K partial products + kai0_adarms_combine (sum, gated residual, adaRMS) ==
+    kai0_gemm_bf16 with the fused gate/residual epilogue followed by kai0_adarms_fwd; bit-stable across launches."""
+    rpb, S_ld, row0 = 50, 72, 11
+    nb = M // rpb
+    a_buf = rnd(nb * S_ld, K, seed=1)
+    w = rnd(N, K, seed=2, scale=0.05)
+    gate = rnd(nb, N, seed=3)
+    res = rnd(M, N, seed=4)
+    mod = rnd(nb, 3 * N, dtype=F32, seed=5, scale=0.3)
+    x_ref = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a_buf, w, x_ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_map=(rpb, S_ld, row0), gate=gate, gate_rpb=rpb,
+             gate_ld=N, residual=res, ldr=N)
+    y_ref, g_ref = ops.adarms(x_ref, mod, rpb, 1e-6)
+    ws = ops.skinny_workspace(M, N, split, dev())
+    outs = []
+    for _ in range(2):
+        ws.fill_(float("nan"))
+        ops.skinny_gemm(a_buf, w, M=M, N=N, K=K, lda=K, ldw=K, split_k=split, workspace=ws, a_map=(rpb, S_ld, row0))
+        outs.append(ops.adarms_combine(ws, gate, res, mod, rpb, 1e-6))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    x, y, g = outs[0]
+    assert torch.equal(g, g_ref)
+    assert rel_err(x, x_ref) < 2e-3 and rel_err(y, y_ref) < 3e-3
+    # adaRMS of the combined x itself is exact
+    y2, _ = ops.adarms(x, mod, rpb, 1e-6)
+    assert torch.equal(y, y2)
+
+
+def test_skinny_qkv_rope_segments(ops):
+    """fused q|k|v projection + RoPE written through the row map into three buffers == separate GEMMs + kai0_rope_inplace."""
+    B, Hs, P, S_ld, H, HD, K = 1, 50, 30, 88, 8, 256, 1024
+    M = B * Hs
+    x = rnd(M, K, seed=1)
+    wq, wk, wv = rnd(H * HD, K, seed=2, scale=0.05), rnd(HD, K, seed=3, scale=0.05), rnd(HD, K, seed=4, scale=0.05)
+    wqkv = torch.cat([wq, wk, wv], 0).contiguous()
+    pos = (torch.arange(Hs, device=dev(), dtype=torch.int32) + 777).view(B, Hs).contiguous()
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, HD, 2, device=dev(), dtype=F32) / HD))).to(BF16).float()
+    # reference path
+    q_ref = torch.zeros(B, S_ld, H * HD, dtype=BF16, device=dev())
+    k_ref = torch.zeros(B, S_ld, HD, dtype=BF16, device=dev())
+    v_ref = torch.zeros(B, S_ld, HD, dtype=BF16, device=dev())
+    for w_, dst, width in ((wq, q_ref, H * HD), (wk, k_ref, HD), (wv, v_ref, HD)):
+        ops.gemm(x, w_, dst, M=M, N=width, K=K, lda=K, ldb=K, ldc=width, c_map=(Hs, S_ld, P))
+    ops.rope_(q_ref, pos, inv_freq, B, Hs, S_ld, P, H, HD)
+    ops.rope_(k_ref, pos, inv_freq, B, Hs, S_ld, P, 1, HD)
+    # fused path
+    q = torch.zeros_like(q_ref)
+    k = torch.zeros_like(k_ref)
+    v = torch.zeros_like(v_ref)
+    cos, sin = ops.rope_table(pos, inv_freq)
+    N = (H + 2) * HD
+    ops.skinny_gemm(x, wqkv, M=M, N=N, K=K, lda=K, ldw=K, mode=1, pair_stride=HD // 2,
+                    segs=[(q, H * HD, 0, H * HD, 1), (k, HD, H * HD, H * HD + HD, 1), (v, HD, H * HD + HD, N, 0)],
+                    c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2)
+    for a, b, name in ((q, q_ref, "q"), (k, k_ref, "k"), (v, v_ref, "v")):
+        assert rel_err(a, b) < 3e-3, name
+        assert torch.equal(a[:, :P], b[:, :P]) and torch.equal(a[:, P + Hs:], b[:, P + Hs:]), name  # untouched rows
+
+
+def test_skinny_geglu(ops):
+    M, K, F = 50, 1024, 4096
+    x = rnd(M, K, seed=1)
+    wg, wu = rnd(F, K, seed=2, scale=0.05), rnd(F, K, seed=3, scale=0.05)
+    wgu = torch.cat([wg, wu], 0).contiguous()
+    h = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, segs=[(h, F, 0, F, 0)])
+    g = (x.float() @ wg.float().t()).to(BF16).float()
+    u = (x.float() @ wu.float().t()).to(BF16).float()
+    ref = (torch.nn.functional.gelu(g, approximate="tanh").to(BF16).float() * u).to(BF16)
+    assert_close_bf16(h, ref.float(), what="skinny geglu", tol=1e-2)
+
+
+@pytest.mark.parametrize("B,Hs,P", [(1, 50, 968), (2, 50, 200), (1, 3, 29)])
+def test_attn_decode_matches_gemm_softmax_gemm(ops, B, Hs, P):
+    """one-launch decode attention (transposed value cache) == logits GEMM + masked softmax + P V GEMM."""
+    H, HD = 8, 256
+    S = P + Hs
+    S_ld = (S + 31) // 32 * 32
+    q = rnd(B, S_ld, H * HD, seed=1)
+    k = rnd(B, S_ld, HD, seed=2)
+    v = rnd(B, S_ld, HD, seed=3)
+    vt = v.transpose(1, 2).contiguous()
+    g = torch.Generator().manual_seed(4)
+    pad = torch.rand(B, S, generator=g) > 0.1
+    pad[:, P:] = True
+    att = torch.zeros(B, S, dtype=torch.bool)
+    att[:, P] = True
+    from kai0_amd.model import build_mask_codes
+
+    qcode, kcode, _ = build_mask_codes(pad.to(dev()), att.to(dev()))
+    M = Hs * H
+    # reference: three launches
+    scores = torch.empty(B, M, S_ld, dtype=BF16, device=dev())
+    ops.gemm(q, k, scores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=B, sA=(S_ld * H * HD, 0), sB=(S_ld * HD, 0),
+             sC=(M * S_ld, 0), scale=HD**-0.5, a_off_elems=P * H * HD)
+    from kai0_amd import _lib
+
+    _lib.call("kai0_softmax_mask_fwd", scores.data_ptr(), scores.data_ptr(), qcode.data_ptr(), kcode.data_ptr(), B, Hs, H, S,
+              S_ld, M * S_ld, P, qcode.stride(0), kcode.stride(0), ops._stream())
+    ref = torch.zeros(B, S_ld, H * HD, dtype=BF16, device=dev())
+    ops.gemm(scores, v, ref, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=B, sA=(M * S_ld, 0),
+             sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=P * H * HD)
+    out = torch.zeros_like(ref)
+    ops.attn_decode(q, k, vt, out, qcode, kcode, batch=B, rows=M, H=H, HD=HD, Sk=S, q0=P, q_bs=S_ld * H * HD, k_bs=S_ld * HD,
+                    k_ld=HD, k_rows=S_ld, vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)
+    out2 = torch.zeros_like(ref)
+    ops.attn_decode(q, k, vt, out2, qcode, kcode, batch=B, rows=M, H=H, HD=HD, Sk=S, q0=P, q_bs=S_ld * H * HD, k_bs=S_ld * HD,
+                    k_ld=HD, k_rows=S_ld, vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)
+    assert torch.equal(out, out2)
+    assert torch.equal(out[:, :P], ref[:, :P]) and torch.equal(out[:, S:], ref[:, S:])  # only the query rows are written
+    assert rel_err(out[:, P:S], ref[:, P:S]) < 3e-3
+    # fp32 ground truth
+    qf = q[:, P:S].float().view(B, Hs, H, HD)
+    logits = (torch.einsum("bshd,bkd->bshk", qf, k[:, :S].float()).to(BF16).float() * HD**-0.5).to(BF16).float()
+    allowed = kcode[:, None, :S] <= qcode[:, P:S, None]
+    logits = logits.masked_fill(~allowed[:, :, None, :], float("-inf"))
+    pr = torch.softmax(logits, -1).to(BF16).float()
+    gt = torch.einsum("bshk,bkd->bshd", pr, v[:, :S].float()).reshape(B, Hs, H * HD)
+    assert rel_err(out[:, P:S], gt) < 4e-3
+
+
+def test_skinny_transposed_value_segment(ops):
+    B, Hs, P, S_ld, HD, K = 2, 50, 30, 96, 256, 1024
+    M = B * Hs
+    x = rnd(M, K, seed=1)
+    w = rnd(2 * HD, K, seed=2, scale=0.05)
+    a = torch.zeros(B, S_ld, HD, dtype=BF16, device=dev())
+    bt = torch.zeros(B, HD, S_ld, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, w, M=M, N=2 * HD, K=K, lda=K, ldw=K, mode=1, pair_stride=HD // 2,
+                    segs=[(a, HD, 0, HD, 0), (bt, S_ld, HD, 2 * HD, 2)], c_map=(Hs, S_ld, P))
+    ref = torch.zeros(B, S_ld, HD, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, w[HD:].contiguous(), M=M, N=HD, K=K, lda=K, ldw=K, mode=1, pair_stride=HD // 2,
+                    segs=[(ref, HD, 0, HD, 0)], c_map=(Hs, S_ld, P))
+    assert torch.equal(bt.transpose(1, 2), ref)
+    src = rnd(3, 40, 64, seed=5)
+    dst = torch.zeros(3, 64, 48, dtype=BF16, device=dev())
+    ops.transpose_strided(src, dst, R=40, C=64, src_ld=64, dst_ld=48, batch=3, src_bs=40 * 64, dst_bs=64 * 48)
+    assert torch.equal(dst[:, :, :40], src.transpose(1, 2)) and not bool(dst[:, :, 40:].any())
