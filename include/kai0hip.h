@@ -100,6 +100,15 @@ typedef struct kai0_gemm_desc {
     int64_t workspace_bytes;
     const void* aux1; /* act 2/3: bf16 [rows][ldc], addressed like C */
     const void* aux2; /* act 3 */
+    /* nseg > 0 (plain bf16 epilogue, batch 1): output columns [seg[i].n_begin, seg[i+1].n_begin) go to seg[i].dst
+     * (leading dimension seg[i].ld, rows through the C row map) instead of C — one GEMM over stacked q|k|v weights
+     * writing the padded q buffer and the K / V caches directly. */
+    int32_t nseg, _pad2;
+    struct {
+        void* dst;
+        int64_t ld;
+        int32_t n_begin, _pad;
+    } seg[3];
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);

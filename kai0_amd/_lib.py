@@ -19,6 +19,10 @@ c_i64 = C.c_int64
 c_f = C.c_float
 
 
+class GemmSeg(C.Structure):
+    _fields_ = [("dst", c_p), ("ld", c_i64), ("n_begin", C.c_int32), ("_pad", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     """Mirror of `kai0_gemm_desc` (include/kai0hip.h)."""
 
@@ -37,6 +41,7 @@ class GemmDesc(C.Structure):
         ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64), ("sR1", c_i64), ("sR2", c_i64),
         ("split_k", C.c_int32), ("_pad1", C.c_int32), ("workspace", c_p), ("workspace_bytes", c_i64),
         ("aux1", c_p), ("aux2", c_p),
+        ("nseg", C.c_int32), ("_pad2", C.c_int32), ("seg", GemmSeg * 3),
     ]  # fmt: skip
 
 

@@ -6,6 +6,8 @@
 #include "../../include/kai0hip.h"
 #include <limits.h>
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
 namespace {
 
 __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
@@ -95,11 +97,24 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* sco
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
                 ld8(sp + ci * 8, v[c]);
+                int kc8[8];
+                if (qcode) {  // key codes of this chunk: two 16-B loads when whole and aligned, else clamped scalars
+                    const int32_t* kp = kcode + (int64_t)b * kld + ci * 8;
+                    if (ci * 8 + 8 <= Sk && (((uintptr_t)kp) & 15) == 0) {
+                        const i32x4 k0 = *reinterpret_cast<const i32x4*>(kp);
+                        const i32x4 k1 = *reinterpret_cast<const i32x4*>(kp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { kc8[e] = k0[e]; kc8[4 + e] = k1[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) kc8[e] = kcode[(int64_t)b * kld + min(ci * 8 + e, Sk - 1)];
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int j = ci * 8 + e;
                     bool ok = j < Sk;
-                    if (ok && qcode) ok = kcode[(int64_t)b * kld + j] <= qc;
+                    if (qcode) ok = ok && kc8[e] <= qc;
                     v[c][e] = ok ? v[c][e] : -INFINITY;
                     m = fmaxf(m, v[c][e]);
                 }

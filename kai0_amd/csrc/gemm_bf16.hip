@@ -63,6 +63,10 @@ struct GemmArgs {
     int64_t ldr, sR1, sR2;
     int tiles_m, tiles_n;
     int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
+    int nseg;              // > 0: bf16 output columns are routed to up to 3 destinations (fused q|k|v projection)
+    bf16_t* seg_dst[3];
+    int64_t seg_ld[3];
+    int seg_begin[3];
     float* ws;             // split-K workspace [batch*split_k][M][N] f32
     int split_k, k_chunk;  // split-K: blockIdx.y = z * split_k + s, split s owns k in [s*k_chunk, min(K, (s+1)*k_chunk))
 };
@@ -117,10 +121,12 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
     } else if (p.act == 2) {
         // GeGLU forward fused into the up-projection GEMM: v = u; pre_out <- u; C <- bf16(bf16(gelu(g)) * u)
-        bf16x8 uv;
+        if (p.pre_out != nullptr) {  // u is only needed by the backward
+            bf16x8 uv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) uv[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = uv;
+            for (int e = 0; e < 8; ++e) uv[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = uv;
+        }
         const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.aux1 + cz + orow * p.ldc + ccol);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = R(R(gelu_tanh_f(bf2f(gv[e]))) * v[e]);
@@ -160,6 +166,12 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
     } else {
         bf16_t* cp = reinterpret_cast<bf16_t*>(cbase) + cz + orow * p.ldc + ccol;
+        if (p.nseg > 0) {
+            int si = 0;
+            if (p.nseg > 1 && ccol >= p.seg_begin[1]) si = 1;
+            if (p.nseg > 2 && ccol >= p.seg_begin[2]) si = 2;
+            cp = p.seg_dst[si] + orow * p.seg_ld[si] + (ccol - p.seg_begin[si]);
+        }
         if (p.accumulate) {
             bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
 #pragma unroll
@@ -524,8 +536,18 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
     KAI0_REQUIRE(d->act >= 0 && d->act <= 3, "kai0_gemm_bf16: unknown act %d", d->act);
-    KAI0_REQUIRE(d->act < 2 || (d->pre_out && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
+    KAI0_REQUIRE(d->act < 2 || ((d->pre_out || d->act == 2) && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
                  "kai0_gemm_bf16: act=%d (fused GeGLU) needs pre_out and aux inputs, bf16 output", d->act);
+    KAI0_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "kai0_gemm_bf16: nseg=%d", d->nseg);
+    if (d->nseg > 0) {
+        KAI0_REQUIRE(!d->out_f32 && !d->accumulate && (d->batch <= 1) && d->act < 2 && !d->pre_out && (d->N % 8) == 0,
+                     "kai0_gemm_bf16: column segments need a plain bf16 epilogue, batch 1");
+        for (int i = 0; i < d->nseg; ++i)
+            KAI0_REQUIRE(d->seg[i].dst && (d->seg[i].ld % 8) == 0 && (d->seg[i].n_begin % 8) == 0 &&
+                             ((uintptr_t)d->seg[i].dst % 16) == 0 && d->seg[i].n_begin == (i ? d->seg[i].n_begin : 0) &&
+                             (i == 0 || d->seg[i].n_begin > d->seg[i - 1].n_begin),
+                         "kai0_gemm_bf16: segment %d (dst, ld %% 8, ascending n_begin %% 8, first at 0)", i);
+    }
     {
         // operands are addressed with 32-bit byte offsets below a 2 GiB buffer descriptor (per batch entry)
         const int64_t a_rows = d->a_rpb ? ((int64_t)((d->a_kc ? d->M : d->K) / d->a_rpb) + 1) * d->a_bs + d->a_off
@@ -557,6 +579,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.gate = (const bf16_t*)d->gate; p.gate_rpb = d->gate_rpb; p.gate_ld = d->gate_ld;
     p.accumulate = d->accumulate;
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
+    p.nseg = d->nseg;
+    for (int i = 0; i < 3; ++i) {
+        p.seg_dst[i] = i < d->nseg ? (bf16_t*)d->seg[i].dst : nullptr;
+        p.seg_ld[i] = i < d->nseg ? d->seg[i].ld : 0;
+        p.seg_begin[i] = i < d->nseg ? d->seg[i].n_begin : 0;
+    }
     p.split_k = 1;
     p.k_chunk = d->K;
     const int split = d->split_k > 1 ? d->split_k : 1;

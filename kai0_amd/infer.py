@@ -73,6 +73,7 @@ class InferenceEngine:
         self._weights_tag = self._fingerprint()
         if self.skinny:
             self._build_skinny()
+        self._build_stacked()
         self._times_dev = {}
         self._graph = None
         self._graph_steps = None
@@ -88,6 +89,76 @@ class InferenceEngine:
         srcs = [w for l in ex.layers for w in (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
                                                 l.mlp.gate_proj.weight, l.mlp.up_proj.weight)]  # fmt: skip
         return tuple((p.data_ptr(), p._version) for p in srcs)
+
+    def _build_stacked(self):
+        """q|k|v weights (and biases) stacked once per engine: one GEMM launch per attention block instead of three.
+        (+0.2 GB SigLIP, +0.2 GB Gemma; the originals stay the checkpoint-visible parameters.)"""
+        vt = self.pe.paligemma.model.vision_tower.vision_model
+        self.sg_wqkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
+                        for l in vt.encoder.layers]  # fmt: skip
+        self.sg_bqkv = [torch.cat([l.self_attn.q_proj.bias, l.self_attn.k_proj.bias, l.self_attn.v_proj.bias], 0).contiguous()
+                        for l in vt.encoder.layers]  # fmt: skip
+        lm = self.pe.paligemma.model.language_model
+        self.lm_wqkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
+                        for l in lm.layers]  # fmt: skip
+
+    def _lin(self, x, w, *, bias=None, residual=None, act=0, split=None, aux1=None):
+        """flat Linear for the prefix / SigLIP passes: launches matter more than occupancy here, so the contraction is
+        only split when there are fewer than ~100 output tiles."""
+        M, K = x.shape
+        N = w.shape[0]
+        if split is None:
+            tiles = ((M + 127) // 128) * ((N + 127) // 128)
+            split = 1 if tiles >= 100 else pick_split_k(M, N, K)
+        out = torch.empty((M, N), dtype=BF16, device=self.dev)
+        gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=residual, ldr=N, act=act, aux1=aux1,
+             split_k=split)
+        return out
+
+    def _siglip(self, image):
+        """SigLIP tower for inference (modeling_siglip.py:271-281,325-460,756-778): stacked q|k|v projection, attention
+        straight off the stacked buffer, no probabilities written, GELU / bias / residual in the GEMM epilogues."""
+        pe = self.pe
+        vt = pe.paligemma.model.vision_tower.vision_model
+        sc = pe.siglip_cfg
+        n = image.shape[0]
+        S = vt.embeddings.num_patches
+        NH, HD = sc.num_heads, sc.hidden_size // sc.num_heads
+        E = NH * HD
+        emb = vt.embeddings
+        x = ops.patch_embed(image.contiguous(), emb.patch_embedding.weight, emb.patch_embedding.bias,
+                            emb.position_embedding.weight, sc.patch_size)  # fmt: skip
+        scale = HD**-0.5
+        for l, layer in enumerate(vt.encoder.layers):
+            h = ops.layernorm(x, layer.layer_norm1.weight, layer.layer_norm1.bias, layer.layer_norm1.eps)
+            qkv = self._lin(h, self.sg_wqkv[l], bias=self.sg_bqkv[l])
+            a = torch.empty((n * S, E), dtype=BF16, device=self.dev)
+            ops.attn_fwd(qkv, qkv[:, E:], qkv[:, 2 * E:], a, None, rows=S, Sk=S, HD=HD, H=1, batch=n * NH, batch_inner=NH,
+                         ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, sQ=(S * 3 * E, HD), sK=(S * 3 * E, HD), sV=(S * 3 * E, HD),
+                         sO=(S * E, HD), scale=scale)  # fmt: skip
+            x = self._lin(a, layer.self_attn.out_proj.weight, bias=layer.self_attn.out_proj.bias, residual=x)
+            h = ops.layernorm(x, layer.layer_norm2.weight, layer.layer_norm2.bias, layer.layer_norm2.eps)
+            f = self._lin(h, layer.mlp.fc1.weight, bias=layer.mlp.fc1.bias, act=1)
+            x = self._lin(f, layer.mlp.fc2.weight, bias=layer.mlp.fc2.bias, residual=x)
+        x = ops.layernorm(x, vt.post_layernorm.weight, vt.post_layernorm.bias, vt.post_layernorm.eps)
+        proj = pe.paligemma.model.multi_modal_projector.linear
+        return self._lin(x, proj.weight, bias=proj.bias).view(n, S, -1)
+
+    def _embed_prefix(self, images, img_masks, lang_tokens, lang_masks):
+        """PI0Pytorch.embed_prefix (pi0_pytorch.py:186-235) over the inference SigLIP tower."""
+        from .model import PrefixAssembleFn
+
+        pe = self.pe
+        B, ncam = lang_tokens.shape[0], len(images)
+        feats = self._siglip(torch.cat(images, dim=0))
+        n_img, D = feats.shape[1], feats.shape[2]
+        lang = ops.embed(pe.paligemma.model.language_model.embed_tokens.weight, lang_tokens, ops.sqrt_scale(D))
+        T = lang_tokens.shape[1]
+        P = ncam * n_img + T
+        embs = PrefixAssembleFn.apply(feats.reshape(ncam * B * n_img, D), lang, B, ncam, n_img, T)
+        pad = torch.cat([m[:, None].expand(B, n_img) for m in img_masks] + [lang_masks.to(torch.bool)], dim=1)
+        att = torch.zeros((B, P), dtype=torch.bool, device=pad.device)
+        return embs.view(B, P, D), pad, att
 
     def _build_skinny(self):
         ex = self.pe.gemma_expert.model
@@ -150,7 +221,7 @@ class InferenceEngine:
     def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks):
         model, pe = self.model, self.pe
         B, P, Hs = self.B, self.P, self.Hs
-        prefix, ppad, patt = model.embed_prefix(images, img_masks, lang_tokens, lang_masks)
+        prefix, ppad, patt = self._embed_prefix(images, img_masks, lang_tokens, lang_masks)
         dev = prefix.device
         spad = torch.ones((B, Hs), dtype=torch.bool, device=dev)
         satt = torch.zeros((B, Hs), dtype=torch.bool, device=dev)
@@ -166,23 +237,29 @@ class InferenceEngine:
         inv_freq = lm.rope_inv_freq()
         H, HD, S_ld = self.H, self.HD, self.S_ld
         xp = prefix.reshape(B * P, self.Dp)
+        NQ = H * HD
+        M = B * P
         for l, layer in enumerate(lm.layers):
             hp = ops.rmsnorm(xp, layer.input_layernorm.weight, layer.input_layernorm.eps)
             at = layer.self_attn
-            self._proj_into(hp, at.k_proj, self.k_cache[l], P, 0, HD)
-            self._proj_into(hp, at.v_proj, self.v_cache[l], P, 0, HD)
-            ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
             if l == self.L - 1:
-                break  # nothing consumes the last prefix layer's attention / MLP output
-            self._proj_into(hp, at.q_proj, self.q_buf, P, 0, H * HD)
+                # nothing consumes the last prefix layer's attention / MLP output: only its K and V rows are needed
+                gemm(hp, self.lm_wqkv[l][NQ:], self.k_cache[l], M=M, N=2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=HD,
+                     c_map=(P, S_ld, 0), segs=[(self.k_cache[l], HD, 0), (self.v_cache[l], HD, HD)],
+                     split_k=pick_split_k(M, 2 * HD, self.Dp))  # fmt: skip
+                ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
+                break
+            # stacked q|k|v projection written straight into the padded q buffer and the K / V caches
+            gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
+                 c_map=(P, S_ld, 0), segs=[(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)])  # fmt: skip
+            ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
             ops.rope_(self.q_buf, self.pos_prefix, inv_freq, B, P, S_ld, 0, H, HD)
             self._attend(l, 0, P, P, qcode, kcode)
             xp = self._oproj(at.o_proj, P, 0, residual=xp)
             hp = ops.rmsnorm(xp, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
-            g = ops.linear_fwd(hp, layer.mlp.gate_proj.weight)
-            u = ops.linear_fwd(hp, layer.mlp.up_proj.weight)
-            _lib.call("kai0_geglu_fwd", g.data_ptr(), u.data_ptr(), g.data_ptr(), g.numel(), ops._stream())
-            xp = ops.linear_fwd(g, layer.mlp.down_proj.weight, residual=xp)
+            g = self._lin(hp, layer.mlp.gate_proj.weight)
+            hmid = self._lin(hp, layer.mlp.up_proj.weight, act=2, aux1=g)  # GeGLU in the epilogue
+            xp = ops.linear_fwd(hmid, layer.mlp.down_proj.weight, residual=xp)
 
     def _modulations(self, times: list[float]):
         """time embedding -> time MLP -> adaRMS `dense` for every step at once (rows = step*B + b)."""

@@ -53,7 +53,7 @@ def gemm(
     scale: float = 1.0, act: int = 0, pre_out: torch.Tensor | None = None, gate: torch.Tensor | None = None,
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
-    aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None,
+    aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -97,6 +97,10 @@ def gemm(
         d.ldr = ldr
         d.sR1, d.sR2 = sR
     d.accumulate = int(accumulate)
+    if segs:  # [(dst, ld, n_begin)]: output columns routed to several destinations
+        d.nseg = len(segs)
+        for i, (dst, ld, nb) in enumerate(segs):
+            d.seg[i].dst, d.seg[i].ld, d.seg[i].n_begin = dst.data_ptr(), ld, nb
     if split_k > 1:
         ws = _workspace(batch * split_k * M * N * 4, A.device)
         d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel()
