@@ -196,9 +196,14 @@ __device__ __forceinline__ void lds_barrier() {
 // Block tile = (WM*MT*16) x (WN*NT*16) x 64, WM x WN waves, each wave MT x NT MFMA 16x16x32 tiles.
 // PP (ping-pong, 8-wave tile only): the waves of tile-row 0 and tile-row 1 (one wave of each per SIMD) run one barrier
 //   slot apart, so in every slot one group issues its 32 MFMAs while the other issues LDS-DMA and ds_reads.
-template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP>
+// NS = LDS stages of the plain (non-PP) loop.  2: one K-tile of prefetch, enough when a second block on the CU (or the
+//   sheer length of a 256x256 tile's MFMA burst) covers the load latency.  4 (128x128 tile, 128 KiB): three K-tiles in
+//   flight with a counted vmcnt — for grids of <= 1 block per CU (B = 1 inference GEMMs), where a 2-stage loop runs at
+//   one memory latency per K-tile.
+template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
+    static_assert(NS >= 2 && (!PP || NS == 2), "stages");
     constexpr int NWAVES = WM * WN;
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
     constexpr int A_TILE = TBM * 128, B_TILE = TBN * 128;  // bytes: [rows][64] or [64][cols] bf16
@@ -384,14 +389,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         }
         if (grp == 0) lds_barrier();  // re-align the two groups
     } else {
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-
+        // iteration kt: [tile kt landed (counted vmcnt) | barrier | issue tile kt+NS-1 into the slot tile kt-1 just left |
+        // compute tile kt].  The barrier orders both the RAW on tile kt and the WAR on the slot being refilled.
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) stage(st, st);
+        int slot_c = 0, slot_p = NS - 1;  // slot being computed / slot being refilled
         for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
-            const char* ta = smem + buf * STAGE;
+            if constexpr (NS == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (NA + NB)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_barrier();
+            if (kt + NS - 1 < nk && p.ablate != 1) stage(kt + NS - 1, slot_p);
+            const char* ta = smem + slot_c * STAGE;
             const char* tb = ta + A_TILE;
     #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -410,10 +423,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                             acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
+            slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            slot_p = slot_p + 1 == NS ? 0 : slot_p + 1;
         }
-
+        lds_barrier();  // the epilogue slabs alias the stage buffers
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -486,17 +499,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-template <int WM, int WN, int MT, int NT, bool PP>
+template <int WM, int WN, int MT, int NT, bool PP, int NS = 2>
 int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
-    constexpr int LDS = 2 * (TBM + TBN) * 128;
+    constexpr int LDS = NS * (TBM + TBN) * 128;
     p.tiles_m = (d->M + TBM - 1) / TBM;
     p.tiles_n = (d->N + TBN - 1) / TBN;
     dim3 grid(p.tiles_m * p.tiles_n, batch * p.split_k, 1), block(WM * WN * 64, 1, 1);
 #define KAI0_LAUNCH(AK, BK_)                                                                                      \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
-        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP>;                                                 \
+        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS>;                                              \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             if (e != hipSuccess) {                                                                                \
@@ -607,8 +620,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // measured on the MLP shapes: the ping-pong schedule wins for NT (+3..8 %) and loses for the transpose-read
     // layouts (their load slot is longer than the MFMA slot), so only NT uses it
     const bool pp = forced ? forced == 5 : (d->a_kc && d->b_kc);
+    // few 128x128 tiles (at most one block per CU): nothing else hides the load latency -> 4-stage pipeline
+    const int64_t small_blocks = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch * (split > 1 ? split : 1);
+    const bool deep = forced ? forced == 2 : (small_blocks <= 256 && p.k_chunk >= 256);
     if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
+    else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);
     else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);
     if (rc) return rc;
     rc = kai0_check_launch("kai0_gemm_bf16");
