@@ -200,16 +200,23 @@ __device__ __forceinline__ void lds_barrier() {
 //   sheer length of a 256x256 tile's MFMA burst) covers the load latency.  4 (128x128 tile, 128 KiB): three K-tiles in
 //   flight with a counted vmcnt — for grids of <= 1 block per CU (B = 1 inference GEMMs), where a 2-stage loop runs at
 //   one memory latency per K-tile.
-template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2>
+// BKT = K-tile depth.  64 everywhere except the ring schedule (PP, NS = 4, BKT = 32): 4 slots of 32 KiB, three
+//   32-deep sub-tiles in flight, every load slot carries 2 DMA pieces + 12 fragment reads and every MFMA slot 32 MFMAs
+//   + 2 DMA pieces, with nothing conditional inside the loop (tail pieces are issued out of range = zero fill).
+template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
-    static_assert(NS >= 2 && (!PP || NS == 2), "stages");
+    static_assert(NS >= 2 && (!PP || NS == 2 || (NS == 4 && BKT == 32)), "stages");
+    static_assert(BKT == 64 || BKT == 32, "K-tile depth");
+    constexpr int BK = BKT;
     constexpr int NWAVES = WM * WN;
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
-    constexpr int A_TILE = TBM * 128, B_TILE = TBN * 128;  // bytes: [rows][64] or [64][cols] bf16
+    constexpr int A_TILE = TBM * BK * 2, B_TILE = TBN * BK * 2;  // bytes: [rows][BK] or [BK][cols] bf16
     constexpr int STAGE = A_TILE + B_TILE;
-    constexpr int NA = TBM / 8 / NWAVES;          // A DMA pieces (1 KiB) per wave per K-tile
-    constexpr int NB = TBN / 8 / NWAVES;
+    constexpr int NA = A_TILE / 1024 / NWAVES;    // A DMA pieces (1 KiB) per wave per K-tile
+    constexpr int NB = B_TILE / 1024 / NWAVES;
+    constexpr int KC_CPR = BK / 8;                // K-contiguous tile: 16-B chunks per row (8 / 4) ...
+    constexpr int KC_RPP = 64 / KC_CPR;           // ... and rows per DMA piece (8 / 16)
     constexpr int A_ROWB = TBM * 2, B_ROWB = TBN * 2;  // bytes per k-row of a contraction-strided tile (256 / 512)
     constexpr int A_LPR = A_ROWB / 16, B_LPR = B_ROWB / 16;  // 16-B chunks (= lanes) per such row
     constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;    // k-rows per DMA piece
@@ -257,11 +264,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     // contraction-strided tile [64 k][cols] (256- or 512-B rows): piece q covers RPP k-rows; lane -> k-row
     //   q*RPP + lane/LPR, slot lane%LPR holding source chunk slot^(key(row)<<1)  (key: see above).
     uint32_t a_off[NA], b_off[NB];  // byte offsets from the operand base; OOB = this lane's chunk lies outside
-    const int kc_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // KC: k offset (elements) of this lane's chunk in the K-tile
+    // KC: k offset (elements) of this lane's chunk in the K-tile.  BK = 64: slot lane&7 of row lane>>3 holds source chunk
+    // slot ^ (row & 7).  BK = 32 (64-B rows): slot lane&3 of row lane>>2 holds chunk slot ^ (row & 8 ? 3 : 0), which makes
+    // the four 16-lane groups of a ds_read_b128 (rows 0-3/12-15 with rows 4-11 of the next chunk) hit 16 distinct slots.
+    const int kc_chunk = BK == 64 ? ((lane & 7) ^ (lane >> 3)) * 8 : ((lane & 3) ^ (((lane >> 2) & 8) ? 3 : 0)) * 8;
     if constexpr (A_KC) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int R = m0 + (wave * NA + j) * 8 + (lane >> 3);
+            const int R = m0 + (wave * NA + j) * KC_RPP + lane / KC_CPR;
             a_off[j] = R < p.M ? (uint32_t)((p.amap(R) * p.lda + kc_chunk) * 2) : OOB;
         }
     } else {
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     if constexpr (B_KC) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int R = n0 + (wave * NB + j) * 8 + (lane >> 3);
+            const int R = n0 + (wave * NB + j) * KC_RPP + lane / KC_CPR;
             b_off[j] = R < p.N ? (uint32_t)((p.bmap(R) * p.ldb + kc_chunk) * 2) : OOB;
         }
     } else {
@@ -319,6 +329,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         }
     };
 
+    // one 1-KiB piece of a K-tile (idx < NA: A pieces, then B pieces): source offset (VALU, computed ahead of time) and
+    // the bare DMA instruction, so that pieces can be dropped between MFMAs with nothing but an s_mov m0 around them
+    auto piece_off = [&](int kt, int idx) -> uint32_t {
+        const int k0 = kbeg + kt * BK;
+        const bool kc_in = (k0 + kc_chunk) < kend;
+        if (idx < NA) {
+            if constexpr (A_KC) {
+                return kc_in ? a_off[idx] + (uint32_t)k0 * 2 : OOB;
+            } else {
+                const int kr = k0 + (wave * NA + idx) * A_RPP + lane / A_LPR;
+                return kr < kend ? a_off[idx] + (uint32_t)p.amap(kr) * lda2 : OOB;
+            }
+        } else {
+            const int j = idx - NA;
+            if constexpr (B_KC) {
+                return kc_in ? b_off[j] + (uint32_t)k0 * 2 : OOB;
+            } else {
+                const int kr = k0 + (wave * NB + j) * B_RPP + lane / B_LPR;
+                return kr < kend ? b_off[j] + (uint32_t)p.bmap(kr) * ldb2 : OOB;
+            }
+        }
+    };
+    auto piece_issue = [&](uint32_t off, int slot, int idx) {
+        if (idx < NA) glds16(a_rsrc, off, smem + slot * STAGE + wave * (NA * 1024) + idx * 1024);
+        else glds16(b_rsrc, off, smem + slot * STAGE + A_TILE + wave * (NB * 1024) + (idx - NA) * 1024);
+    };
+
     // ---- fragment read offsets (bytes inside an operand tile), fixed per thread -----------------
     const int l15 = lane & 15, g = lane >> 4;
     // KC: row = w*(T*16) + t*16 + l15 ; chunk = ks*4 + g ; addr = row*128 + ((chunk ^ (row&7)) << 4)
@@ -335,8 +372,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     auto load_frag = [&](const char* tile, bool kc, int rowb, int col0, int ks) -> bf16x8 {
         if (kc) {
             const int row = col0 + l15;
-            const int chunk = ks * 4 + g;
-            const int off = row * 128 + ((chunk ^ (row & 7)) << 4);
+            const int off = BK == 64 ? row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)
+                                     : row * 64 + ((g ^ ((row & 8) ? 3 : 0)) << 4);
             return *reinterpret_cast<const bf16x8*>(tile + off);
         } else {
             const int chunk = (col0 >> 3) + ((l15 & 3) >> 1);
@@ -349,10 +386,70 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     };
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if constexpr (PP) {
-        // Barrier clock b0, b1, ...: per K-tile t group 0 runs  L0(t) |b| M0(t) |b| L1(t) |b| M1(t) |b|  and group 1 the same
-        // sequence one barrier later.  Lk = [k = 0: issue the whole DMA of tile t+1] + the 12 fragment reads of k-half
-        // k; Mk = its 32 MFMAs.
+    if constexpr (PP && NS == 4) {
+        // Ring schedule.  Sub-tile u (32 deep) lives in slot u & 3.  Group g (= wm) runs  L(u) |b| M(u) |b|  at barrier
+        // slots 2u+g, 2u+1+g: in every slot one group issues MFMAs while the other reads fragments.
+        //   L(u): fragment reads of sub-tile u, then DMA pieces 0,1 of sub-tile u+3;  M(u): 32 MFMAs with pieces 2,3 of
+        //   sub-tile u+3 dropped in after MFMA rows 2 and 5 (their offsets were computed in L(u)).
+        //  * Why: one LDS-DMA piece costs its wave 100-180 cycles next to ds_reads and ~60 between MFMAs; the former
+        //    schedule put all 8 pieces of a 64-deep tile in one load slot (~1300 cycles against the partner's 512 of
+        //    MFMA), and the loop without DMA ran at 1.7-2.0 PFLOP/s against 1.1 with it.
+        //  * WAR: slot (u+3)&3 held sub-tile u-1, last read in group 1's L(u-1) (slot 2u-1, retired by the lgkmcnt(0)
+        //    in front of its barrier); the earliest piece of u+3 is issued in group 0's L(u) (slot 2u).
+        //  * RAW: sub-tile u+1 is first read in slot 2u+2, so every wave drains its pieces of u+1 before the barrier that
+        //    ends slot 2u+1 — group 0 at the end of M(u) with pieces of u+2, u+3 (8) still in flight, group 1 at the end
+        //    of L(u) with those of u+2 and the first two of u+3 (6).  Counts stay exact in the tail because pieces past
+        //    the end are still issued (out-of-range offset: zero fill into a slot nobody reads).
+        constexpr int NP = NA + NB;
+        static_assert(NP == 4 && BK == 32, "ring schedule: 4 pieces per 32-deep sub-tile");
+        const int grp = wm;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) piece_issue(piece_off(u, pi), u, pi);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        lds_barrier();
+        if (grp == 1) lds_barrier();  // stagger group 1 by one slot
+        for (int u = 0; u < nk; ++u) {
+            const int slot = u & 3, pslot = (u + 3) & 3;
+            const char* ta = smem + slot * STAGE;
+            const char* tb = ta + A_TILE;
+            bf16x8 bfr[NT], af[MT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + t * 16, 0);
+            uint32_t poff[NP];
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) poff[pi] = p.ablate == 1 ? OOB : piece_off(u + 3, pi);
+            __builtin_amdgcn_sched_barrier(0);
+            piece_issue(poff[0], pslot, 0);
+            piece_issue(poff[1], pslot, 1);
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            lds_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                if (i == 2 || i == 5) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece_issue(poff[i == 2 ? 2 : 3], pslot, i == 2 ? 2 : 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            lds_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill pieces must land before the slabs reuse LDS
+        if (grp == 0) lds_barrier();  // re-align the two groups
+        lds_barrier();
+    } else if constexpr (PP) {
+        // Two-buffer ping-pong (kept for comparison, KAI0_GEMM_CFG=5).  Barrier clock b0, b1, ...: per K-tile t group 0 runs
+        // L0(t) |b| M0(t) |b| L1(t) |b| M1(t) |b|  and group 1 the same sequence one barrier later.  Lk = [k = 0: issue the
+        // whole DMA of tile t+1] + the 12 fragment reads of k-half k; Mk = its 32 MFMAs.
         //  * RAW: tile t+1 is first read after barrier 4t+3 (group 0's L0(t+1)); every wave drains its own DMA before
         //    that barrier (group 0 at the end of M1(t), group 1 at the end of L1(t)), >= 2 slots after issuing it.
         //  * WAR: the DMA of tile t+1 overwrites the buffer of tile t-1, last read in group 1's L1(t-1) and retired by
@@ -367,7 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             const char* ta = smem + buf * STAGE;
             const char* tb = ta + A_TILE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 32; ++ks) {
                 if (ks == 0 && kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
                 bf16x8 bfr[NT], af[MT];
 #pragma unroll
@@ -407,7 +504,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             const char* ta = smem + slot_c * STAGE;
             const char* tb = ta + A_TILE;
     #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 32; ++ks) {
                 bf16x8 bfr[NT];
     #pragma unroll
                 for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
@@ -499,17 +596,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-template <int WM, int WN, int MT, int NT, bool PP, int NS = 2>
+template <int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64>
 int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
-    constexpr int LDS = NS * (TBM + TBN) * 128;
+    constexpr int LDS = NS * (TBM + TBN) * BKT * 2;
     p.tiles_m = (d->M + TBM - 1) / TBM;
     p.tiles_n = (d->N + TBN - 1) / TBN;
     dim3 grid(p.tiles_m * p.tiles_n, batch * p.split_k, 1), block(WM * WN * 64, 1, 1);
 #define KAI0_LAUNCH(AK, BK_)                                                                                      \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
-        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS>;                                              \
+        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS, BKT>;                                              \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             if (e != hipSuccess) {                                                                                \
@@ -592,6 +689,8 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.gate = (const bf16_t*)d->gate; p.gate_rpb = d->gate_rpb; p.gate_ld = d->gate_ld;
     p.accumulate = d->accumulate;
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
+    static const int ablate = [] { const char* e = getenv("KAI0_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    p.ablate = ablate;  // diagnostics: 1 = no DMA in the K loop (compute + LDS-read ceiling)
     p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {
         p.seg_dst[i] = i < d->nseg ? (bf16_t*)d->seg[i].dst : nullptr;
@@ -623,7 +722,13 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // few 128x128 tiles (at most one block per CU): nothing else hides the load latency -> 4-stage pipeline
     const int64_t small_blocks = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch * (split > 1 ? split : 1);
     const bool deep = forced ? forced == 2 : (small_blocks <= 256 && p.k_chunk >= 256);
-    if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
+    // forced: 4 = 256x256 plain, 5 = 256x256 two-buffer ping-pong (all layouts), 6 = ring for NT only, 7 = ring for all
+    // measured (MLP shapes, random data): the ring wins +21 % for the transpose-read layout (TN wgrads: 512-B source rows,
+    // so a 32-deep sub-tile still moves whole cache lines) and loses up to 17 % for NT (64-B source rows = half lines,
+    // every line crosses the fabric twice), which keeps the two-buffer ping-pong.
+    const bool ring = forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc);
+    if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);
+    else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
     else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);
     else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);
