@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-trace stats of the bench command and of one action chunk, plus three PMC
+# passes over one training step.  Only small text summaries are kept (gpurun copies back <= 64 MiB).
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/summary; rm -rf $OUT; mkdir -p $OUT
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency"
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -o train -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
+python tools/prof_summary.py $(find /tmp/prof_train -name "*.db" | head -1) > $OUT/train_kernel_stats.md 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_inf -o inf -- python tools/infer_once.py 5 1 > $OUT/infer_under_rocprof.log 2>&1
+python tools/prof_summary.py $(find /tmp/prof_inf -name "*.db" | head -1) > $OUT/infer_kernel_stats.md 2>&1
+python tools/infer_timeline.py $(find /tmp/prof_inf -name "*.db" | head -1) > $OUT/infer_timeline.txt 2>&1
+ONE="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-gemm-timing"
+for C in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA:mfma"; do
+  CN="${C%%:*}"; DN="${C##*:}"
+  timeout 900 rocprofv3 --pmc $CN --kernel-trace -d /tmp/pmc_$DN -o p --output-format csv -- $ONE > $OUT/pmc_$DN.log 2>&1
+  python tools/pmc_summary.py /tmp/pmc_$DN 14 > $OUT/pmc_$DN.txt 2>&1
+done
+grep -h '"metric"' $OUT/*.log | cut -c1-600
+ls -la $OUT
