@@ -109,6 +109,12 @@ typedef struct kai0_gemm_desc {
         int64_t ld;
         int32_t n_begin, _pad;
     } seg[3];
+    /* act 4 — softmax backward fused into dP = dO V^T (modeling_gemma.py:243-248 / modeling_siglip.py:325-345 through
+     * autograd): C = bf16( (P * (acc - D[row])) * scale ) with P = aux1 (bf16, addressed like C) and
+     * D = rowvec[z1*rv_s1 + z2*rv_s2 + row*rv_ld] = sum_d dO[row][d] * O[row][d] (kai0_rowdot_bf16), which equals the
+     * row's <dP, P>.  dP is taken from the f32 accumulator: it is never rounded and never written. */
+    const float* rowvec;
+    int64_t rv_s1, rv_s2, rv_ld;
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
@@ -254,6 +260,8 @@ int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_freq, int B,
 int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode, const int32_t* kcode,
                           int B, int Sq, int H, int Sk, int64_t ld, int64_t batch_stride, int q0,
                           int64_t qcode_ld, int64_t kcode_ld, kai0_stream_t stream);
+/* out[r] = sum_d a[r][d] * b[r][d] in f32 (rows of D contiguous bf16 elements, D % 8 == 0): the softmax-backward row term */
+int kai0_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int D, kai0_stream_t stream);
 /* dscores = bf16( (probs * (dprobs - sum_j dprobs*probs)) * scale ).  dprobs is bf16 or (dprobs_f32) f32:
  * with near-uniform attention dprobs - <dprobs,probs> cancels catastrophically, so the training path keeps
  * dP = dO V^T in f32 (the reference's autograd rounds it to bf16; this is the more accurate of the two). */

@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int32), ("_pad1", C.c_int32), ("workspace", c_p), ("workspace_bytes", c_i64),
         ("aux1", c_p), ("aux2", c_p),
         ("nseg", C.c_int32), ("_pad2", C.c_int32), ("seg", GemmSeg * 3),
+        ("rowvec", c_p), ("rv_s1", c_i64), ("rv_s2", c_i64), ("rv_ld", c_i64),
     ]  # fmt: skip
 
 
@@ -106,6 +107,7 @@ _PROTOS: dict[str, list] = {
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
     "kai0_softmax_mask_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
+    "kai0_rowdot_bf16": [c_p, c_p, c_p, c_i64, c_i, c_p],
     "kai0_softmax_bwd": [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_f, c_p],
     "kai0_geglu_fwd": [c_p, c_p, c_p, c_i64, c_p],
     "kai0_geglu_bwd": [c_p, c_p, c_p, c_p, c_p, c_i64, c_p],

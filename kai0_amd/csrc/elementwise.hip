@@ -150,6 +150,32 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* sco
     }
 }
 
+// out[r] = sum_d a[r][d] * b[r][d]: 8 bf16 per lane, D/8 lanes per row, rows packed into the wave
+__global__ __launch_bounds__(256) void rowdot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                     float* __restrict__ out, int64_t rows, int D) {
+    const int lpr = D >> 3;  // lanes per row (<= 64 enforced by the host)
+    int span = 1;
+    while (span < lpr) span <<= 1;  // lanes reserved per row (power of two, so xor-shuffles stay inside the row)
+    const int rpw = 64 / span;      // rows per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / span, li = lane - sub * span;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r0 = wave_id * rpw; r0 < rows; r0 += nwaves * rpw) {
+        const int64_t r = r0 + sub;
+        float acc = 0.f;
+        if (r < rows && li < lpr) {
+            float x[8], y[8];
+            ld8(a + r * D + li * 8, x);
+            ld8(b + r * D + li * 8, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += x[e] * y[e];
+        }
+        for (int off = span >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (r < rows && li == 0) out[r] = acc;
+    }
+}
+
 template <bool DP_F32>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ probs, const void* dprobs,
                                                           bf16_t* dscores, int64_t rows, int Sk, int64_t ld,
@@ -525,6 +551,16 @@ KAI0_API int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_
                        (const bf16_t*)scores, (bf16_t*)probs, qcode, kcode, B, Sq, H, Sk, ld, batch_stride, q0,
                        qcode_ld, kcode_ld);
     return kai0_check_launch("kai0_softmax_mask_fwd");
+}
+
+KAI0_API int kai0_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int D, kai0_stream_t stream) {
+    KAI0_REQUIRE(D % 8 == 0 && D >= 8 && D <= 512, "kai0_rowdot_bf16: D=%d must be a multiple of 8, <= 512", D);
+    if (rows <= 0) return 0;
+    int span = 1;
+    while (span < D / 8) span <<= 1;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(ew_grid(rows, 4 * (64 / span))), dim3(256), 0, S_(stream), (const bf16_t*)a,
+                       (const bf16_t*)b, out, rows, D);
+    return kai0_check_launch("kai0_rowdot_bf16");
 }
 
 KAI0_API int kai0_softmax_bwd(const void* probs, const void* dprobs, int dprobs_f32, void* dscores, int64_t rows, int Sk,

@@ -63,6 +63,8 @@ struct GemmArgs {
     int64_t ldr, sR1, sR2;
     int tiles_m, tiles_n;
     int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
+    const float* rowvec;   // act 4: per-row f32 vector D (softmax backward), index z1*rv_s1 + z2*rv_s2 + row*rv_ld
+    int64_t rv_s1, rv_s2, rv_ld;
     int nseg;              // > 0: bf16 output columns are routed to up to 3 destinations (fused q|k|v projection)
     bf16_t* seg_dst[3];
     int64_t seg_ld[3];
@@ -87,12 +89,23 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t vof
 // The fused epilogue on 8 consecutive columns [ccol, ccol+8) of output row `row` (v = f32 accumulators), shared by the
 // GEMM kernel and the split-K reduction.  Order and rounding points: see kai0hip.h.
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int row, int ccol, int64_t cz, int64_t rz,
-                                          void* cbase, bool raw_f32) {
+                                          int64_t vz, void* cbase, bool raw_f32) {
     // raw_f32: f32 output keeps the raw accumulator (no bf16 rounding points): gradients that must not be quantised
     // before a cancelling reduction (softmax backward) and split-K partial tiles.
     const bool rnd = !raw_f32;
     auto R = [rnd](float x) { return rnd ? rbf(x) : x; };
     const int64_t orow = p.cmap(row);
+    if (p.act == 4) {
+        // softmax backward fused into dP = dO V^T: C <- bf16( (P * (dP - D[row])) * scale ), D = rowsum(dO * O) (= the
+        // row's <dP, P>), dP straight from the f32 accumulator (never rounded, never written)
+        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(p.aux1 + cz + orow * p.ldc + ccol);
+        const float dsum = p.rowvec[vz + (int64_t)row * p.rv_ld];
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf((bf2f(pv[e]) * (v[e] - dsum)) * p.scale);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(cbase) + cz + orow * p.ldc + ccol) = ov;
+        return;
+    }
     if (p.bias != nullptr) {
         if (p.bias_f32) {
             const float* bp = reinterpret_cast<const float*>(p.bias) + ccol;
@@ -532,6 +545,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     float* slab = reinterpret_cast<float*>(smem + wave * 16384);
     const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
+    const int64_t vz = z1 * p.rv_s1 + z2 * p.rv_s2;
     const int ccol = n0 + wn * 64 + (lane & 7) * 8;
     // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
     // zero-filled) and are stored into the row padding the host guarantees (ldc >= round_up(N, 8)).
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 *reinterpret_cast<f32x4*>(wp) = v0;
                 *reinterpret_cast<f32x4*>(wp + 4) = v1;
             } else {
-                epilogue8(p, v, row, ccol, cz, rz, p.C, p.out_f32 != 0);
+                epilogue8(p, v, row, ccol, cz, rz, vz, p.C, p.out_f32 != 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -580,7 +594,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int n8 = (p.N + 7) >> 3;
     const int64_t total = (int64_t)p.M * n8;
     const float* w0 = p.ws + (int64_t)z * p.split_k * p.M * p.N;
-    const int64_t cz = z1 * p.sC1 + z2 * p.sC2, rz = z1 * p.sR1 + z2 * p.sR2;
+    const int64_t cz = z1 * p.sC1 + z2 * p.sC2, rz = z1 * p.sR1 + z2 * p.sR2, vz = z1 * p.rv_s1 + z2 * p.rv_s2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int row = (int)(i / n8);
         const int col = (int)(i - (int64_t)row * n8) * 8;
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             acc[0] += a[0]; acc[1] += a[1]; acc[2] += a[2]; acc[3] += a[3];
             acc[4] += b[0]; acc[5] += b[1]; acc[6] += b[2]; acc[7] += b[3];
         }
-        epilogue8(p, acc, row, col, cz, rz, p.C, p.out_f32 != 0);
+        epilogue8(p, acc, row, col, cz, rz, vz, p.C, p.out_f32 != 0);
     }
 }
 
@@ -645,13 +659,16 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
-    KAI0_REQUIRE(d->act >= 0 && d->act <= 3, "kai0_gemm_bf16: unknown act %d", d->act);
-    KAI0_REQUIRE(d->act < 2 || ((d->pre_out || d->act == 2) && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
+    KAI0_REQUIRE(d->act >= 0 && d->act <= 4, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act != 4 || (d->aux1 && d->rowvec && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
+                 "kai0_gemm_bf16: act=4 (fused softmax backward) needs aux1 = P, rowvec = D, plain bf16 output");
+    KAI0_REQUIRE(d->act < 2 || d->act == 4 || ((d->pre_out || d->act == 2) && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
                  "kai0_gemm_bf16: act=%d (fused GeGLU) needs pre_out and aux inputs, bf16 output", d->act);
     KAI0_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "kai0_gemm_bf16: nseg=%d", d->nseg);
     if (d->nseg > 0) {
         KAI0_REQUIRE(!d->out_f32 && !d->accumulate && (d->batch <= 1) && d->act < 2 && !d->pre_out && (d->N % 8) == 0,
                      "kai0_gemm_bf16: column segments need a plain bf16 epilogue, batch 1");
+        KAI0_REQUIRE(d->act != 4, "kai0_gemm_bf16: column segments and act=4 are exclusive");
         for (int i = 0; i < d->nseg; ++i)
             KAI0_REQUIRE(d->seg[i].dst && (d->seg[i].ld % 8) == 0 && (d->seg[i].n_begin % 8) == 0 &&
                              ((uintptr_t)d->seg[i].dst % 16) == 0 && d->seg[i].n_begin == (i ? d->seg[i].n_begin : 0) &&
@@ -691,6 +708,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
     static const int ablate = [] { const char* e = getenv("KAI0_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;  // diagnostics: 1 = no DMA in the K loop (compute + LDS-read ceiling)
+    p.rowvec = d->rowvec; p.rv_s1 = d->rv_s1; p.rv_s2 = d->rv_s2; p.rv_ld = d->rv_ld;
     p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {
         p.seg_dst[i] = i < d->nseg ? (bf16_t*)d->seg[i].dst : nullptr;

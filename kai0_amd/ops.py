@@ -53,7 +53,7 @@ def gemm(
     scale: float = 1.0, act: int = 0, pre_out: torch.Tensor | None = None, gate: torch.Tensor | None = None,
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
-    aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None,
+    aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None, rowvec=None, rv=(0, 0, 1),
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -97,6 +97,11 @@ def gemm(
         d.ldr = ldr
         d.sR1, d.sR2 = sR
     d.accumulate = int(accumulate)
+    if rowvec is not None:  # act 4: D index = z1*rv[0] + z2*rv[1] + row*rv[2]
+        if rowvec.dtype != F32:
+            raise TypeError("gemm: rowvec must be f32")
+        d.rowvec = rowvec.data_ptr()
+        d.rv_s1, d.rv_s2, d.rv_ld = rv
     if segs:  # [(dst, ld, n_begin)]: output columns routed to several destinations
         d.nseg = len(segs)
         for i, (dst, ld, nb) in enumerate(segs):
@@ -186,6 +191,16 @@ def transpose_strided(src, dst, *, R, C, src_ld, dst_ld, batch=1, src_bs=0, dst_
     """dst[z][c][r] = src[z][r][c] (kai0_transpose_strided_bf16)."""
     _lib.call("kai0_transpose_strided_bf16", src.data_ptr(), dst.data_ptr(), R, C, src_ld, dst_ld, batch, src_bs, dst_bs,
               _stream())  # fmt: skip
+
+
+def rowdot(a, b, D: int):
+    """out[r] = sum_d a[r, d] * b[r, d] in f32 over rows of D contiguous bf16 elements (a, b contiguous, same shape)."""
+    if a.dtype != BF16 or b.dtype != BF16 or not a.is_contiguous() or not b.is_contiguous() or a.numel() != b.numel():
+        raise _lib.Kai0HipError("rowdot: two contiguous bf16 tensors of the same size expected")
+    rows = a.numel() // D
+    out = torch.empty((rows,), dtype=F32, device=a.device)
+    _lib.call("kai0_rowdot_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, D, _stream())
+    return out
 
 
 def rope_table(pos, inv_freq):
@@ -916,13 +931,13 @@ class JointAttentionFn(torch.autograd.Function):
             _copy_rows(att, o, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * H * HD, 0, H * HD)
             outs.append(o)
             r0 += Li
-        ctx.save_for_backward(q_all, k_all, v_all, probs, pos, inv_freq)
+        ctx.save_for_backward(q_all, k_all, v_all, probs, pos, inv_freq, att)
         ctx.cfg = (Bn, S, S_ld, H, HD, seg_lens, scale)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        q_all, k_all, v_all, probs, pos, inv_freq = ctx.saved_tensors
+        q_all, k_all, v_all, probs, pos, inv_freq, att = ctx.saved_tensors
         Bn, S, S_ld, H, HD, seg_lens, scale = ctx.cfg
         dev = q_all.device
         M = S * H
@@ -935,15 +950,13 @@ class JointAttentionFn(torch.autograd.Function):
         dv_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
              sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
-        # dP[b] [M, S_ld] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K])
-        # f32 on purpose: dP - <dP, P> cancels when attention is diffuse (see kai0_softmax_bwd in kai0hip.h)
-        dprobs = torch.empty(probs.shape, dtype=F32, device=dev)
-        gemm(datt, v_all, dprobs, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
-             sB=(S_ld * HD, 0), sC=(M * S_ld, 0))  # fmt: skip
+        # dS[b] [M, S_ld] = softmax'(dP), dP[b] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K]): the softmax
+        # backward runs in the GEMM epilogue on the f32 accumulator (dP is never rounded or written; the row term
+        # <dP, P> is computed as rowsum(dO * O), kai0hip.h act 4)
+        dsum = rowdot(datt, att, HD)  # [Bn * S_ld * H]
         dscores = torch.empty_like(probs)
-        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), 1, dscores.data_ptr(), Bn * M, S, S_ld, scale,
-                  _stream())  # fmt: skip
-        del dprobs
+        gemm(datt, v_all, dscores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
+             sB=(S_ld * HD, 0), sC=(M * S_ld, 0), act=4, aux1=probs, rowvec=dsum, rv=(S_ld * H, 0, 1), scale=scale)  # fmt: skip
         # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
         dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
         gemm(dscores, k_all, dq_all, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
@@ -985,13 +998,13 @@ class SiglipAttentionFn(torch.autograd.Function):
         out = torch.empty((n_img * S, E), dtype=BF16, device=dev)
         attn_fwd(q, k, v, out, probs, rows=S, Sk=S, HD=HD, H=1, batch=n_img * NH, batch_inner=NH, ldq=E, ldk=E, ldv=E,
                  ldo=E, ldp=S_ld, sQ=(S * E, HD), sK=(S * E, HD), sV=(S * E, HD), sO=(S * E, HD), sP=S * S_ld, scale=scale)
-        ctx.save_for_backward(q, k, v, probs)
+        ctx.save_for_backward(q, k, v, probs, out)
         ctx.cfg = (n_img, S, S_ld, NH, HD, scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, probs = ctx.saved_tensors
+        q, k, v, probs, out = ctx.saved_tensors
         n_img, S, S_ld, NH, HD, scale = ctx.cfg
         dev = q.device
         E = NH * HD
@@ -1002,12 +1015,11 @@ class SiglipAttentionFn(torch.autograd.Function):
         dv = torch.empty_like(v)
         gemm(probs, dout, dv, M=S, N=HD, K=S, a_kc=False, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
              sA=sP, sB=sE, sC=sE)  # fmt: skip
-        dprobs32 = torch.empty(probs.shape, dtype=F32, device=dev)
-        gemm(dout, v, dprobs32, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=nb, batch_inner=NH, sA=sE, sB=sE, sC=sP)
-        dprobs = torch.empty_like(probs)
-        _lib.call("kai0_softmax_bwd", probs.data_ptr(), dprobs32.data_ptr(), 1, dprobs.data_ptr(), nb * S, S, S_ld, scale,
-                  _stream())  # fmt: skip
-        del dprobs32
+        # dS = softmax'(dO V^T) in the GEMM epilogue (act 4); row term = rowsum(dO * O), rows enumerated (image, token, head)
+        dsum = rowdot(dout, out, HD)  # [n_img * S * NH]
+        dprobs = torch.zeros_like(probs) if S_ld != S else torch.empty_like(probs)
+        gemm(dout, v, dprobs, M=S, N=S, K=HD, lda=E, ldb=E, ldc=S_ld, batch=nb, batch_inner=NH, sA=sE, sB=sE, sC=sP, act=4,
+             aux1=probs, rowvec=dsum, rv=(S * NH, 1, NH), scale=scale)  # fmt: skip
         dq = torch.empty_like(q)
         gemm(dprobs, k, dq, M=S, N=HD, K=S, a_kc=True, b_kc=False, lda=S_ld, ldb=E, ldc=E, batch=nb, batch_inner=NH,
              sA=sP, sB=sE, sC=sE)  # fmt: skip

@@ -816,3 +816,31 @@ def test_skinny_transposed_value_segment(ops):
     dst = torch.zeros(3, 64, 48, dtype=BF16, device=dev())
     ops.transpose_strided(src, dst, R=40, C=64, src_ld=64, dst_ld=48, batch=3, src_bs=40 * 64, dst_bs=64 * 48)
     assert torch.equal(dst[:, :, :40], src.transpose(1, 2)) and not bool(dst[:, :, 40:].any())
+
+
+def test_gemm_softmax_backward_epilogue_and_rowdot(ops):
+    """act 4: dS = bf16((P * (dO V^T - D)) * scale) with D = rowdot(dO, O) == softmax backward of the f32 dP with the
+    row term <dP, P> (equal up to the bf16 rounding of O = P V)."""
+    from kai0_amd import _lib
+
+    B, M, S, HD = 2, 200, 136, 64
+    g = torch.Generator().manual_seed(0)
+    probs = torch.softmax(torch.randn(B, M, S, generator=g) * 2, -1).to(BF16).to(dev())
+    v = rnd(B, S, HD, seed=1)
+    do = rnd(B, M, HD, seed=2)
+    o = torch.bmm(probs.float(), v.float()).to(BF16)
+    scale = HD**-0.5
+    dsum = ops.rowdot(do, o, HD)
+    assert rel_err(dsum, (do.float() * o.float()).sum(-1).reshape(-1)) < 1e-5
+    ds = torch.empty_like(probs)
+    ops.gemm(do, v, ds, M=M, N=S, K=HD, lda=HD, ldb=HD, ldc=S, batch=B, sA=(M * HD, 0), sB=(S * HD, 0), sC=(M * S, 0), act=4,
+             aux1=probs, rowvec=dsum, rv=(M, 0, 1), scale=scale)
+    dp = torch.bmm(do.float(), v.float().transpose(1, 2))
+    ref = probs.float() * (dp - (dp * probs.float()).sum(-1, keepdim=True)) * scale
+    assert rel_err(ds, ref) < 6e-3
+    # and against the two-kernel path it replaces (f32 dP written, kai0_softmax_bwd)
+    dp32 = torch.empty(B, M, S, dtype=F32, device=dev())
+    ops.gemm(do, v, dp32, M=M, N=S, K=HD, lda=HD, ldb=HD, ldc=S, batch=B, sA=(M * HD, 0), sB=(S * HD, 0), sC=(M * S, 0))
+    ds2 = torch.empty_like(probs)
+    _lib.call("kai0_softmax_bwd", probs.data_ptr(), dp32.data_ptr(), 1, ds2.data_ptr(), B * M, S, S, scale, ops._stream())
+    assert rel_err(ds, ds2) < 6e-3
