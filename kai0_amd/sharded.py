@@ -27,6 +27,7 @@ from __future__ import annotations
 import math
 
 import functools
+import os
 
 import torch
 import torch.distributed as dist
@@ -54,7 +55,7 @@ class HipShardOps:
 
 
 class _Bucket:
-    def __init__(self, params, dtype, world, rank, device, align=256):
+    def __init__(self, params, dtype, world, rank, device, align=256, alias_shard=True):
         self.params = params
         self.dtype = dtype
         self.offsets = []
@@ -73,7 +74,7 @@ class _Bucket:
         lo = rank * self.shard
         self.param_shard = self.flat_param[lo : lo + self.shard]
         # one GPU: the "shard" is the whole buffer — alias it instead of copying
-        self.grad_shard = self.flat_grad if world == 1 else torch.zeros(self.shard, dtype=dtype, device=device)
+        self.grad_shard = self.flat_grad if (world == 1 and alias_shard) else torch.zeros(self.shard, dtype=dtype, device=device)
         for p, o in zip(params, self.offsets):
             # producers that can write a gradient in place (LinearFn wgrad, EmbedFn) pick this up
             p._kai0_grad_out = self.flat_grad[o : o + p.numel()].view(p.shape)
@@ -100,7 +101,10 @@ class ShardedDataParallel:
         if not uniq:
             raise ValueError("no trainable parameters")
         self.device = uniq[0].device
-        self.backend = dist.get_backend(group) if world_size > 1 else "none"
+        # KAI0_FORCE_COLLECTIVES=1: run the reduce-scatter / all-gather calls even with one rank (validates the RCCL call
+        # pattern on a single-GPU box; tools/nccl_same_gpu_probe.py)
+        self.collectives = world_size > 1 or (os.environ.get("KAI0_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+        self.backend = dist.get_backend(group) if self.collectives else "none"
         # gradients become ready in (roughly) reverse registration order: pack buckets in that order
         self.buckets: list[_Bucket] = []
         for dtype in (BF16, F32):
@@ -109,10 +113,10 @@ class ShardedDataParallel:
                 cur.append(p)
                 cur_bytes += p.numel() * p.element_size()
                 if cur_bytes >= bucket_bytes:
-                    self.buckets.append(_Bucket(cur, dtype, world_size, rank, self.device))
+                    self.buckets.append(_Bucket(cur, dtype, world_size, rank, self.device, alias_shard=not self.collectives))
                     cur, cur_bytes = [], 0
             if cur:
-                self.buckets.append(_Bucket(cur, dtype, world_size, rank, self.device))
+                self.buckets.append(_Bucket(cur, dtype, world_size, rank, self.device, alias_shard=not self.collectives))
         other = [p for p in uniq if p.dtype not in (BF16, F32)]
         if other:
             raise TypeError(f"unsupported parameter dtype {other[0].dtype}")
@@ -128,7 +132,7 @@ class ShardedDataParallel:
 
     # ------------------------------------------------------------------------------------------ collectives
     def _reduce_scatter_avg(self, b: _Bucket):
-        if self.world == 1:
+        if not self.collectives:
             return None  # grad_shard aliases flat_grad
         if self.backend == "nccl":  # RCCL
             return dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -139,7 +143,7 @@ class ShardedDataParallel:
         return None
 
     def _all_gather(self, b: _Bucket):
-        if self.world == 1:
+        if not self.collectives:
             return None
         if self.backend == "nccl":
             return dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True)
