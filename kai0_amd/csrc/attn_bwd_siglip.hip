@@ -1,0 +1,287 @@
+// attn_bwd_siglip.hip — backward of SigLIP's unmasked multi-head attention (modeling_siglip.py:325-345 through autograd),
+// one block per (image, head): S = 256 tokens, HD = 72.
+//
+// The GEMM formulation spent 4 batched launches per layer on 1536 tiny problems (256x256x72: two K-tiles each, all
+// prologue / epilogue) — ~0.57 ms per layer for 58 GFLOP.  Here a head's whole backward runs out of one block's LDS:
+//     D  = rowsum(dO * O)                                   (= <dP, P> per query row)
+//     dP = dO V^T (f32, never stored);  dS = bf16((P * (dP - D)) * scale)
+//     dQ = dS K ;  dK = dS^T Q ;  dV = P^T dO               (f32 accumulate, bf16 out)
+// gfx950 mapping (8 waves):
+//   phase A, wave = 32 query rows: dP^T tiles = MFMA(V rows, dO rows) with the V rows permuted so that lane (q, g) ends up
+//     with 8 CONSECUTIVE keys — exactly the 16-B slice of P it needs and exactly the B fragment of dQ^T += K^T dS^T, whose
+//     A fragments (K^T) come from the row-major K tile in LDS through ds_read_b64_tr_b16;
+//   phase B, wave = 32 keys: dP tiles = MFMA(dO rows permuted, V rows) give lane (key, g) 8 consecutive queries; P^T comes
+//     from a 32-row P chunk in LDS through the transpose read; dK^T += Q^T dS and dV^T += dO^T P take Q^T / dO^T fragments
+//     from the LDS tiles the same way.  No operand is transposed through memory, P is read twice, nothing else is re-read.
+#include "common.h"
+#include "../../include/kai0hip.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int SB_S = 256, SB_HD = 72;
+constexpr int SB_LDR = 104;           // LDS row stride (elements) of the [256][72] tiles: 208 B puts 16 rows on 16 distinct
+                                      // 16-B bank groups; columns 72..103 are zero (MFMA contraction padded to 96, output to 80)
+constexpr int SB_PLD = 264;           // row stride of a P chunk [32][256]
+constexpr int SB_TILE = SB_S * SB_LDR * 2;         // 53 248 B
+constexpr int SB_PCH = 32 * SB_PLD * 2;            // 16 896 B
+constexpr int SB_LDS = 2 * SB_TILE + 2 * SB_PCH + SB_S * 4;
+
+struct SbArgs {
+    const bf16_t *q, *k, *v, *dO, *O, *P;
+    bf16_t *dq, *dk, *dv;
+    int NH;
+    int64_t E;
+    float scale;
+    int dbg;  // diagnostics (KAI0_SB_DBG): 1 = stop after staging + D, 2 = stop after phase A, 3 = skip phase A
+};
+
+__device__ __forceinline__ bf16x8 sb_zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// two [256][72] global tiles (row stride E) -> LDS [256][SB_LDR], pad columns zeroed; 512 threads.  All 2 x 7 loads of a
+// thread are issued before the first LDS store (one global latency per staging, not one per 16-byte chunk).
+__device__ __forceinline__ void sb_stage2(const bf16_t* __restrict__ src0, const bf16_t* __restrict__ src1, int64_t E,
+                                          bf16_t* dst0, bf16_t* dst1, int tid) {
+    constexpr int NIT = (SB_S * 13 + 511) / 512;  // 13 chunks of 8 per row: 9 data + 4 zero
+    bf16x8 v0[NIT], v1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
+        const int r = idx / 13, c = idx - r * 13;
+        const bool ld = idx < SB_S * 13 && c < 9;
+        v0[it] = ld ? *reinterpret_cast<const bf16x8*>(src0 + (int64_t)r * E + c * 8) : sb_zero8();
+        v1[it] = ld ? *reinterpret_cast<const bf16x8*>(src1 + (int64_t)r * E + c * 8) : sb_zero8();
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
+        if (idx < SB_S * 13) {
+            const int r = idx / 13, c = idx - r * 13;
+            *reinterpret_cast<bf16x8*>(dst0 + r * SB_LDR + c * 8) = v0[it];
+            *reinterpret_cast<bf16x8*>(dst1 + r * SB_LDR + c * 8) = v1[it];
+        }
+    }
+}
+
+// A/B fragment of a row-major LDS tile, contraction along the row: lane (row, g) <- tile[row][32cc + 8g .. +8]
+__device__ __forceinline__ bf16x8 sb_rowfrag(const bf16_t* tile, int row, int cc, int g) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * SB_LDR + 32 * cc + 8 * g);
+}
+// transposed fragment: lane (col c0 + l15, g) <- tile[r0 + 8g .. +8][col]  (two 4x16 transpose reads)
+__device__ __forceinline__ bf16x8 sb_trfrag(const bf16_t* tile, int ld, int r0, int c0, int l15, int g) {
+    const bf16_t* p = tile + (r0 + 8 * g + (l15 >> 2)) * ld + c0 + 4 * (l15 & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(p));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(p + 4 * ld));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sbm[];
+    bf16_t* T0 = reinterpret_cast<bf16_t*>(sbm);                       // phase A: K,  phase B: Q
+    bf16_t* T1 = reinterpret_cast<bf16_t*>(sbm + SB_TILE);             // phase A: V,  phase B: dO
+    bf16_t* Pc = reinterpret_cast<bf16_t*>(sbm + 2 * SB_TILE);         // [2][32][SB_PLD]
+    float* Dl = reinterpret_cast<float*>(sbm + 2 * SB_TILE + 2 * SB_PCH);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, n = bh / p.NH, h = bh - n * p.NH;
+    const int64_t base = (int64_t)n * SB_S * p.E + (int64_t)h * SB_HD;  // element offset of row 0 of this head
+    const bf16_t* qg = p.q + base;
+    const bf16_t* kg = p.k + base;
+    const bf16_t* vg = p.v + base;
+    const bf16_t* dOg = p.dO + base;
+    const bf16_t* Og = p.O + base;
+    const bf16_t* Pg = p.P + (int64_t)bh * SB_S * SB_S;
+
+    // ---- D[q] = sum_d dO[q][d] * O[q][d] ---------------------------------------------------------------
+    {
+        const int qr = tid >> 1, half = tid & 1;
+        float acc = 0.f;
+        bf16x8 a[5], b[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = half * 5 + i;
+            const bool ok = c < 9;
+            a[i] = ok ? *reinterpret_cast<const bf16x8*>(dOg + (int64_t)qr * p.E + c * 8) : sb_zero8();
+            b[i] = ok ? *reinterpret_cast<const bf16x8*>(Og + (int64_t)qr * p.E + c * 8) : sb_zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += bf2f(a[i][e]) * bf2f(b[i][e]);
+        acc += __shfl_xor(acc, 1, 64);
+        if (half == 0) Dl[qr] = acc;
+    }
+    sb_stage2(kg, vg, p.E, T0, T1, tid);
+    __syncthreads();
+
+    // ================= phase A: dQ for query rows [32 wave, +32) ==========================================
+    const int arow = 8 * (l15 >> 2) + (l15 & 3);  // row of a 32-row group fed to A-row l15 of tile 0 (tile 1: + 4)
+    if (p.dbg == 1) return;
+#pragma unroll 1
+    for (int c = p.dbg == 3 ? 2 : 0; c < 2; ++c) {
+        const int q0 = 32 * wave + 16 * c;
+        bf16x8 dof[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            dof[cc] = (32 * cc + 8 * g) < SB_HD ? *reinterpret_cast<const bf16x8*>(dOg + (int64_t)(q0 + l15) * p.E + 32 * cc + 8 * g)
+                                                 : sb_zero8();
+        const float dq_row = Dl[q0 + l15];
+        // this lane's 8 x 8 probabilities of the chunk: all in flight before the first MFMA (the loop is otherwise one
+        // global-load latency per key group)
+        bf16x8 pvs[8];
+#pragma unroll
+        for (int kgp = 0; kgp < 8; ++kgp)
+            pvs[kgp] = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)(q0 + l15) * SB_S + 32 * kgp + 8 * g);
+        f32x4 accq[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kgp = 0; kgp < 8; ++kgp) {
+            const int kb = 32 * kgp;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T1, kb + arow, cc, g), dof[cc], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T1, kb + arow + 4, cc, g), dof[cc], a1, 0, 0, 0);
+            }
+            // lane (q = q0 + l15, g) holds dP for keys kb + 8g + e  (e < 4: a0, e >= 4: a1)
+            const bf16x8 pv = pvs[kgp];
+            bf16x8 ds;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ds[e] = f2bf((bf2f(pv[e]) * ((e < 4 ? a0[e] : a1[e - 4]) - dq_row)) * p.scale);
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt)
+                accq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_trfrag(T0, SB_LDR, kb, 16 * dt, l15, g), ds, accq[dt], 0, 0, 0);
+        }
+        // accq[dt]: lane (q = q0 + l15, g) holds d = 16 dt + 4 g + r
+        bf16_t* dqp = p.dq + base + (int64_t)(q0 + l15) * p.E;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < SB_HD) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(accq[dt][r]);
+                *reinterpret_cast<bf16x4*>(dqp + d0) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (p.dbg == 2) return;
+    // ================= phase B: dK, dV for keys [32 wave, +32) ============================================
+    sb_stage2(qg, dOg, p.E, T0, T1, tid);
+    // V rows of this wave's keys as B fragments (n = key), straight from global (the LDS copy is gone)
+    bf16x8 vfr[2][3];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            vfr[kt][cc] = (32 * cc + 8 * g) < SB_HD
+                              ? *reinterpret_cast<const bf16x8*>(vg + (int64_t)(32 * wave + 16 * kt + l15) * p.E + 32 * cc + 8 * g)
+                              : sb_zero8();
+    f32x4 acck[2][5], accv[2][5];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) acck[kt][dt] = accv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // P chunk staging: 32 rows x 32 chunks of 16 B = 2 per thread
+    const int pr0 = tid >> 5, pc0 = (tid & 31) * 8;  // rows pr0 and pr0 + 16
+    bf16x8 pn0 = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)pr0 * SB_S + pc0);
+    bf16x8 pn1 = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)(pr0 + 16) * SB_S + pc0);
+    *reinterpret_cast<bf16x8*>(Pc + pr0 * SB_PLD + pc0) = pn0;
+    *reinterpret_cast<bf16x8*>(Pc + (pr0 + 16) * SB_PLD + pc0) = pn1;
+    __syncthreads();
+#pragma unroll 1
+    for (int qc = 0; qc < 8; ++qc) {
+        const int qb = 32 * qc;
+        const bf16_t* Pcur = Pc + (qc & 1) * (32 * SB_PLD);
+        if (qc + 1 < 8) {
+            pn0 = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)(qb + 32 + pr0) * SB_S + pc0);
+            pn1 = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)(qb + 48 + pr0) * SB_S + pc0);
+        }
+        bf16x8 dofr[2][3];  // dO rows (permuted) as A fragments of dP
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            dofr[0][cc] = sb_rowfrag(T1, qb + arow, cc, g);
+            dofr[1][cc] = sb_rowfrag(T1, qb + arow + 4, cc, g);
+        }
+        const f32x4 dv0 = *reinterpret_cast<const f32x4*>(Dl + qb + 8 * g);
+        const f32x4 dv1 = *reinterpret_cast<const f32x4*>(Dl + qb + 8 * g + 4);
+        bf16x8 qt[5], dot[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            qt[dt] = sb_trfrag(T0, SB_LDR, qb, 16 * dt, l15, g);
+            dot[dt] = sb_trfrag(T1, SB_LDR, qb, 16 * dt, l15, g);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[0][cc], vfr[kt][cc], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[1][cc], vfr[kt][cc], a1, 0, 0, 0);
+            }
+            // lane (key = 32 wave + 16 kt + l15, g) holds dP for queries qb + 8g + e
+            const bf16x8 pt = sb_trfrag(Pcur, SB_PLD, 0, 32 * wave + 16 * kt, l15, g);
+            bf16x8 ds;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                ds[e] = f2bf((bf2f(pt[e]) * ((e < 4 ? a0[e] : a1[e - 4]) - (e < 4 ? dv0[e] : dv1[e - 4]))) * p.scale);
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) {
+                acck[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[dt], ds, acck[kt][dt], 0, 0, 0);
+                accv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pt, accv[kt][dt], 0, 0, 0);
+            }
+        }
+        if (qc + 1 < 8) {
+            bf16_t* Pnext = Pc + ((qc + 1) & 1) * (32 * SB_PLD);
+            *reinterpret_cast<bf16x8*>(Pnext + pr0 * SB_PLD + pc0) = pn0;
+            *reinterpret_cast<bf16x8*>(Pnext + (pr0 + 16) * SB_PLD + pc0) = pn1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int64_t ro = base + (int64_t)(32 * wave + 16 * kt + l15) * p.E;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < SB_HD) {
+                bf16x4 ok, ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ok[r] = f2bf(acck[kt][dt][r]);
+                    ov[r] = f2bf(accv[kt][dt][r]);
+                }
+                *reinterpret_cast<bf16x4*>(p.dk + ro + d0) = ok;
+                *reinterpret_cast<bf16x4*>(p.dv + ro + d0) = ov;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+KAI0_API int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void* dO, const void* O,
+                                  const void* P, void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD,
+                                  int64_t ldp, float scale, kai0_stream_t stream) {
+    KAI0_REQUIRE(q && k && v && dO && O && P && dq && dk && dv, "kai0_siglip_attn_bwd: null operand");
+    KAI0_REQUIRE(S == SB_S && HD == SB_HD && ldp == SB_S,
+                 "kai0_siglip_attn_bwd: built for S = 256, head_dim = 72, ldp = 256 (got S=%d HD=%d ldp=%lld)", S, HD, (long long)ldp);
+    KAI0_REQUIRE(NH >= 1, "kai0_siglip_attn_bwd: NH");
+    if (n_img <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
+        KAI0_REQUIRE(e == hipSuccess, "kai0_siglip_attn_bwd: cannot reserve %d B of LDS: %s", SB_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    SbArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)P,
+             (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, NH, (int64_t)NH * HD, scale, 0};
+    static const int dbg = [] { const char* e = getenv("KAI0_SB_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    hipLaunchKernelGGL(siglip_attn_bwd_kernel, dim3(n_img * NH), dim3(512), SB_LDS, (hipStream_t)stream, a);
+    return kai0_check_launch("kai0_siglip_attn_bwd");
+}

@@ -14,6 +14,7 @@ is done by libkai0hip.so.  There is deliberately no CPU / eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -878,6 +879,9 @@ def attn_fwd(Q, K, V, O, P, *, rows, Sk, HD, H=1, q0=0, batch=1, batch_inner=1, 
     _lib.call("kai0_attn_fwd", C.byref(d), _stream())
 
 
+_ATTN_FWD_GEMM = os.environ.get("KAI0_ATTN_FWD", "fused") == "gemm"
+
+
 def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H, HD, scale, want_probs=True):
     """Prefix-LM masked multi-query attention over padded buffers (modeling_gemma.py:230-253), one fused kernel.
 
@@ -886,6 +890,18 @@ def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H
     Returns (att [B, S_ld, H*HD] with rows q0..q0+Sq written, probs [B, Sq*H, S_ld] or None)."""
     dev = q_all.device
     M = Sq * H
+    if _ATTN_FWD_GEMM and want_probs and HD % 8 == 0:
+        # three launches: logits GEMM (scale in the epilogue), masked softmax in place, P V GEMM
+        probs = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
+        gemm(q_all, k_all, probs, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
+             sB=(S_ld * HD, 0), sC=(M * S_ld, 0), scale=scale, a_off_elems=q0 * H * HD)  # fmt: skip
+        _lib.call("kai0_softmax_mask_fwd", probs.data_ptr(), probs.data_ptr(), _p(qcode), _p(kcode), Bn, Sq, H, Sk, S_ld,
+                  M * S_ld, q0, qcode.stride(0) if qcode is not None else 0, kcode.stride(0) if kcode is not None else 0,
+                  _stream())  # fmt: skip
+        att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        gemm(probs, v_all, att, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
+             sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD)  # fmt: skip
+        return att, probs
     probs = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev) if want_probs else None
     att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
     attn_fwd(q_all, k_all, v_all, att, probs, rows=M, Sk=Sk, HD=HD, H=H, q0=q0, batch=Bn, ldq=HD, ldk=HD, ldv=HD, ldo=HD,
@@ -985,6 +1001,9 @@ def joint_attention(pos, qcode, kcode, inv_freq, H, HD, seg_lens, qkv):
     return JointAttentionFn.apply(pos, qcode, kcode, inv_freq, H, HD, tuple(seg_lens), *qkv)
 
 
+_SIGLIP_BWD_FUSED = os.environ.get("KAI0_SIGLIP_BWD", "fused") != "gemm"
+
+
 class SiglipAttentionFn(torch.autograd.Function):
     """Unmasked multi-head attention of SigLIP (modeling_siglip.py:325-345): q,k,v flat [N*S, NH*HD] bf16."""
 
@@ -1009,6 +1028,12 @@ class SiglipAttentionFn(torch.autograd.Function):
         dev = q.device
         E = NH * HD
         dout = dout.contiguous()
+        if S == 256 and HD == 72 and S_ld == 256 and _SIGLIP_BWD_FUSED:
+            # the real tower (so400m/14 @ 224): one block per (image, head) runs the whole backward out of LDS
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            _lib.call("kai0_siglip_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), out.data_ptr(),
+                      probs.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), n_img, S, NH, HD, S_ld, scale, _stream())  # fmt: skip
+            return dq, dk, dv, None, None, None, None
         nb = n_img * NH
         sP = (NH * S * S_ld, S * S_ld)
         sE = (S * E, HD)

@@ -844,3 +844,27 @@ def test_gemm_softmax_backward_epilogue_and_rowdot(ops):
     ds2 = torch.empty_like(probs)
     _lib.call("kai0_softmax_bwd", probs.data_ptr(), dp32.data_ptr(), 1, ds2.data_ptr(), B * M, S, S, scale, ops._stream())
     assert rel_err(ds, ds2) < 6e-3
+
+
+def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
+    """real tower shape (S = 256, 16 heads x 72): the one-block-per-head backward == the GEMM formulation == fp32 autograd."""
+    n, S, NH, HD = 3, 256, 16, 72
+    E = NH * HD
+    q, k, v = rnd(n * S, E, seed=1, scale=0.6), rnd(n * S, E, seed=2, scale=0.6), rnd(n * S, E, seed=3)
+    do = rnd(n * S, E, seed=4)
+    outs = {}
+    for mode in (True, False):
+        ops._SIGLIP_BWD_FUSED = mode
+        qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = ops.siglip_attention(qq, kk, vv, n, S, NH, HD)
+        o.backward(do)
+        outs[mode] = (o.detach(), qq.grad, kk.grad, vv.grad)
+    ops._SIGLIP_BWD_FUSED = True
+    for a, b, name in zip(outs[True][1:], outs[False][1:], ("dq", "dk", "dv")):
+        assert rel_err(a, b) < 4e-3, name
+    Q, K, V = (t.float().view(n, S, NH, HD).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    logits = ((Q @ K.transpose(-1, -2)).to(BF16).float() * HD**-0.5).to(BF16).float()
+    O = torch.softmax(logits, -1).to(BF16).float() @ V
+    O.backward(do.float().view(n, S, NH, HD).transpose(1, 2))
+    for got, ref, name in zip(outs[True][1:], (Q.grad, K.grad, V.grad), ("dq", "dk", "dv")):
+        assert rel_err(got.view(n, S, NH, HD).transpose(1, 2), ref) < 1.5e-2, name
