@@ -235,6 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;    // k-rows per DMA piece
     constexpr int GROUP = TBM == 128 ? 8 : 4;
     static_assert(NA >= 1 && NB >= 1 && NT == 4 && (MT % 4) == 0, "unsupported tile configuration");
+    static_assert(A_KC || (64 % A_LPR) == 0, "contraction-strided A needs a power-of-two tile height");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -584,7 +585,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     };
     epi_half(std::integral_constant<int, 0>{});
     if constexpr (MT / 4 > 1) epi_half(std::integral_constant<int, 1>{});
-    static_assert(MT / 4 <= 2, "extend the epilogue halves");
+    if constexpr (MT / 4 > 2) epi_half(std::integral_constant<int, 2>{});
+    static_assert(MT / 4 <= 3, "extend the epilogue parts");
 }
 
 // split-K reduction: sum the f32 partial tiles of a (batch entry, 8-column group) and run the fused epilogue once.
@@ -631,10 +633,16 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
         }                                                                                                         \
         hipLaunchKernelGGL(kern, grid, block, LDS, s, p);                                                         \
     } while (0)
+    constexpr bool MC_A_OK = (64 % (TBM * 2 / 16)) == 0;  // contraction-strided A tiles need whole k-rows per DMA piece
     if (d->a_kc && d->b_kc) KAI0_LAUNCH(true, true);
     else if (d->a_kc && !d->b_kc) KAI0_LAUNCH(true, false);
-    else if (!d->a_kc && d->b_kc) KAI0_LAUNCH(false, true);
-    else KAI0_LAUNCH(false, false);
+    else if constexpr (MC_A_OK) {
+        if (!d->a_kc && d->b_kc) KAI0_LAUNCH(false, true);
+        else KAI0_LAUNCH(false, false);
+    } else {
+        kai0_set_error("kai0_gemm_bf16: this tile configuration needs a K-contiguous A operand");
+        return -3;
+    }
 #undef KAI0_LAUNCH
     return 0;
 }
@@ -745,7 +753,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // so a 32-deep sub-tile still moves whole cache lines) and loses up to 17 % for NT (64-B source rows = half lines,
     // every line crosses the fabric twice), which keeps the two-buffer ping-pong.
     const bool ring = forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc);
-    if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);
+    // forced 8: 384x256x64 plain loop (NT / NN only): 20 % fewer staged bytes per FLOP than 256x256
+    if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
+    else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
     else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);

@@ -7,7 +7,7 @@ if len(sys.argv) > 1:
     from tools.bench_gemm import timeit
     dev = torch.device("cuda:0"); BF16 = torch.bfloat16
     cases = [("NT", 8192, 8192, 8192, 0), ("NT", 30976, 16384, 2048, 0), ("NT", 30976, 2048, 16384, 0),
-             ("TN", 16384, 2048, 30976, 0), ("TN", 2048, 16384, 30976, 0), ("TN", 8192, 8192, 8192, 0)]
+             ("NT", 30976, 2048, 2048, 0), ("NT", 24576, 4304, 1152, 0)]
     for (lay, M, N, K, pad) in cases:
         out = torch.empty(M, N, dtype=BF16, device=dev)
         if lay == "NT":
@@ -19,6 +19,5 @@ if len(sys.argv) > 1:
         ms = timeit(lambda: ops.gemm(a, b, out, M=M, N=N, K=K, ldc=N, **kw), iters=8, warm=4)
         print(f"{sys.argv[1]:8s} {lay} {M}x{N}x{K} pad {pad:3d}: {ms:.3f} ms {2*M*N*K/ms/1e9:.0f} TF/s", flush=True)
 else:
-    for name, extra in (("default", {}), ("cfg7-ring", {"KAI0_GEMM_CFG": "7"}), ("cfg5-pp", {"KAI0_GEMM_CFG": "5"}),
-                        ("ring-abl", {"KAI0_GEMM_CFG": "7", "KAI0_GEMM_ABLATE": "1"})):
+    for name, extra in (("default", {}), ("cfg8-384", {"KAI0_GEMM_CFG": "8"})):
         subprocess.run([sys.executable, __file__, name], env=dict(os.environ, **extra))
