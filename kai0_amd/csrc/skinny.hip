@@ -21,6 +21,7 @@
 //       geglu  : h = bf16( bf16(gelu_tanh(g)) * u ), W = [gate ; up]
 #include "common.h"
 #include "../../include/kai0hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -63,9 +64,11 @@ struct SkinnyArgs {
 constexpr int TM = 64, TN = 32;
 constexpr int RED_LD = TN + 1;  // f32 row stride of a wave's partial tile in LDS (odd: conflict-free column writes)
 
-template <int NC>
-__global__ __launch_bounds__(256, 1) void skinny_kernel(const SkinnyArgs p) {
-    __shared__ float red[4][TM][RED_LD];
+// NW waves share the block's K range (k_blk / NW each, NC chunks of 128): 4 x 2 chunks or 8 x 1 chunk for k_blk = 1024
+// (twice the waves = twice the loads in flight per CU for the launches that cannot split K over blocks), 4 x 1 for 512.
+template <int NC, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void skinny_kernel(const SkinnyArgs p) {
+    __shared__ float red[NW][TM][RED_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void skinny_kernel(const SkinnyArgs p) {
     const int n_sub0 = (tile / per) * (2 * p.pair_stride) + (tile % per) * 16;
     const int n_sub1 = n_sub0 + p.pair_stride;
     const int m0 = mt_blk * TM;
-    const int kw0 = ks * p.k_blk + wave * (p.k_blk >> 2);
+    const int kw0 = ks * p.k_blk + wave * (p.k_blk / NW);
 
     // ---- all fragment loads of this wave's K slice, then the MFMAs --------------------------------
     const bf16_t* w0 = p.W + (int64_t)(n_sub0 + i) * p.ldw + kw0 + 32 * g;
@@ -127,13 +130,19 @@ __global__ __launch_bounds__(256, 1) void skinny_kernel(const SkinnyArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][mt * 16 + 4 * g + r][s * 16 + i] = acc[mt][s][r];
     __syncthreads();
+    if (tid >= 256) return;  // 64 rows x 4 column quads finish the tile
     const int row = tid >> 2, q = tid & 3;
     float v0[4], v1[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        v0[e] = (red[0][row][4 * q + e] + red[1][row][4 * q + e]) + (red[2][row][4 * q + e] + red[3][row][4 * q + e]);
-        v1[e] = (red[0][row][16 + 4 * q + e] + red[1][row][16 + 4 * q + e]) +
-                (red[2][row][16 + 4 * q + e] + red[3][row][16 + 4 * q + e]);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            s0 += red[w][row][4 * q + e];
+            s1 += red[w][row][16 + 4 * q + e];
+        }
+        v0[e] = s0;
+        v1[e] = s1;
     }
 
     // ---- split-K: raw f32 partial products [split][M][N]; the consumer (kai0_adarms_combine) adds them in order ----
@@ -319,10 +328,15 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
         a.ws = (float*)d->workspace;
     }
     const dim3 grid(tiles, S, mtiles);
+    // 8 waves (KAI0_SKINNY_NW8=1) measured identical to 4 on the denoise loop (24.44 vs 24.45 ms per chunk): the q|k|v and
+    // gate|up launches are not short of loads in flight
+    static const int nw8 = [] { const char* e = getenv("KAI0_SKINNY_NW8"); return e ? atoi(e) : 0; }();
     if (a.k_blk == 512)
-        hipLaunchKernelGGL(skinny_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((skinny_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (nw8)
+        hipLaunchKernelGGL((skinny_kernel<1, 8>), grid, dim3(512), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(skinny_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((skinny_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return kai0_check_launch("kai0_gemm_skinny_bf16");
 }
 
