@@ -3,12 +3,22 @@
 THIS FILE IS NOT PART OF THE PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
 leg may import it; nothing under kai0_amd/ does.  It exists to check the HIP path, never to serve it.
 
-Parity status: **parity unpinned by the reference** — the reference ships no golden vectors and no test of
-its PyTorch model (model_test.py:12-24 asserts shapes only), and the reference itself cannot
-be imported in this image (python 3.10 < 3.11, transformers 5.x != patched 4.53.2, no jax/flax).  This
-restatement therefore follows the reference source line by line; every function cites the lines it follows.
-What IS pinned: the integer/boolean logic (masks, position ids) against hand-computed cases from the
-reference docstrings (pi0_pytorch.py:52-81), and the state-dict key set against SURVEY.md §8a16.
+Parity status: the reference ships no golden vectors and no test of its PyTorch model (SURVEY.md §4/§8c:
+model_test.py:12-24 asserts shapes only), and the package cannot be imported in this image (python 3.10 < 3.11,
+transformers 5.x != patched 4.53.2, no jax/flax).  What pins this restatement to the reference instead:
+  * **vectors produced by executing the reference's own code** (tests/golden/make_reference_blocks_golden.py lifts the
+    definitions out of the reference source with `ast` and runs them in the build container; fixture
+    tests/golden/reference_blocks.safetensors; checked bit-exactly in bf16 by tests/test_reference_blocks_cpu.py):
+    make_att_2d_masks + position ids, create_sinusoidal_pos_embedding, GemmaRMSNorm (plain and adaptive),
+    apply_rotary_pos_emb, eager_attention_forward, _gated_residual, GemmaMLP, a whole GemmaDecoderLayer (expert with
+    adaRMS + cached K/V; plain prefix layer), a whole SiglipEncoderLayer, the JOINT prefix+expert forward of
+    PaliGemmaWithExpertModel (gemma_pytorch.py:126-279, two layers, padded prompt, prefix-LM mask) and
+    PI0Pytorch.embed_suffix (pi0.5 branch);
+  * the integer/boolean logic additionally against the hand-worked examples of the reference docstring;
+  * the state-dict key set against SURVEY.md §8a16.
+**Still unpinned by the reference** (followed line by line, every function cites its lines): the SigLIP patch/position
+embedding and projector, embed_prefix's concatenation, the loss glue of forward() and the Euler loop of sample_actions —
+they need the patched HF model classes to run.
 
 Module tree and parameter names mirror the reference exactly so a state_dict moves between this oracle and
 the HIP model unchanged:

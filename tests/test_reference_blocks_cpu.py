@@ -1,0 +1,154 @@
+"""The oracle against vectors produced by EXECUTING THE REFERENCE'S OWN building blocks.
+
+tests/golden/reference_blocks.safetensors holds inputs, weights and outputs of the functions / classes the hot path is made
+of, lifted with `ast` from the reference source and run in the build container (tests/golden/make_reference_blocks_golden.py):
+make_att_2d_masks, create_sinusoidal_pos_embedding (pi0_pytorch.py), GemmaRMSNorm plain + adaptive, apply_rotary_pos_emb,
+eager_attention_forward, _gated_residual, GemmaMLP, a whole GemmaDecoderLayer (expert: adaRMS + cached K/V; prefix: plain)
+(modeling_gemma.py) and a whole SiglipEncoderLayer (modeling_siglip.py).  This is what pins the oracle — and through the
+HIP-vs-oracle tests the kernels — to the reference rather than to our reading of it.  Integer / boolean results must be
+bit-exact; bf16 results must be bit-exact too (same torch ops in the same order); f32 / f64 within 1e-6."""
+
+import os
+import types
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import pi0_oracle as O
+
+G = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_blocks.safetensors"))
+BF = torch.bfloat16
+
+
+def g(prefix):
+    return types.SimpleNamespace(**{k[len(prefix) + 1 :].replace(".", "__"): v for k, v in G.items() if k.startswith(prefix + ".")})
+
+
+def test_mask_construction_and_position_ids_bit_exact():
+    c = g("masks")
+    pad, att = c.pad.bool(), c.att.bool()
+    assert torch.equal(O.make_att_2d_masks(pad, att), c.att2d.bool())
+    assert torch.equal(torch.cumsum(pad, dim=1) - 1, c.position_ids)
+    # and the integer mask codes the HIP kernels use instead of the [S, S] tensor
+    from kai0_amd.model import build_mask_codes
+
+    qcode, kcode, pos = build_mask_codes(pad, att)
+    assert torch.equal(kcode[:, None, :] <= qcode[:, :, None], c.att2d.bool())
+    assert torch.equal(pos.long()[pad], c.position_ids[pad])
+
+
+def test_time_embedding():
+    c = g("sincos")
+    out = O.create_sinusoidal_pos_embedding(c.time, 64, 4e-3, 4.0)
+    assert out.dtype == c.out.dtype == torch.float64 and torch.allclose(out, c.out, rtol=0, atol=1e-12)
+
+
+def test_rmsnorm_plain_and_adaptive():
+    c = g("rms_plain")
+    n = O.GemmaRMSNorm(48)
+    n.weight.data = c.w.clone()
+    assert torch.equal(n(c.x)[0], c.y_bf16)
+    assert torch.allclose(n(c.x.float())[0], c.y_f32, rtol=1e-6, atol=1e-6)
+    c = g("rms_ada")
+    a = O.GemmaRMSNorm(48, cond_dim=32)
+    a.dense.weight.data, a.dense.bias.data = c.dense_w.clone(), c.dense_b.clone()
+    y, gate = a(c.x, c.cond)
+    assert torch.equal(y, c.y) and torch.equal(gate, c.gate)
+
+
+def test_rotary_attention_gated_residual_mlp():
+    c = g("rope")
+    q, k = O.apply_rope(c.q, c.k, c.cos, c.sin)
+    assert torch.equal(q, c.q_out) and torch.equal(k, c.k_out)
+    c = g("attn")
+    assert torch.equal(O.eager_attention(c.q, c.k, c.v, c.mask, 16**-0.5, 8), c.out_bf16)
+    assert torch.allclose(O.eager_attention(c.q.float(), c.k.float(), c.v.float(), c.mask, 16**-0.5, 8), c.out_f32, atol=1e-6)
+    c = g("gated")
+    assert torch.equal(O.gated_residual(c.x, c.y, c.gate), c.out) and torch.equal(O.gated_residual(c.x, c.y, None), c.out_nogate)
+    c = g("mlp")
+    m = O.GemmaMLP(48, 96).to(BF)
+    m.gate_proj.weight.data, m.up_proj.weight.data, m.down_proj.weight.data = c.gate_w.clone(), c.up_w.clone(), c.down_w.clone()
+    assert torch.equal(m(c.x), c.y)
+
+
+def _load_layer(model_layer, c):
+    sd = {k[3:].replace("__", "."): v for k, v in vars(c).items() if k.startswith("w__")}
+    missing, unexpected = model_layer.load_state_dict(sd, strict=True), None
+    for name, p in model_layer.named_parameters():
+        p.data = sd[name].clone()  # keep the stored dtypes (bf16 weights, f32 norms)
+    return model_layer
+
+
+@pytest.mark.parametrize("kind", ["layer_expert", "layer_prefix"])
+def test_whole_decoder_layer(kind):
+    """GemmaDecoderLayer.forward driven through the oracle's GemmaModel.forward_single (one layer); the final norm the oracle
+    applies on top is undone by comparing against reference-layer-output -> oracle-final-norm."""
+    c = g(kind)
+    cfg = O.GemmaCfg(width=48, depth=1, mlp_dim=96, num_heads=8, num_kv_heads=1, head_dim=16)
+    adaptive = kind == "layer_expert"
+    model = O.GemmaModel(cfg, vocab=8, use_adarms=adaptive, with_embed=False)
+    _load_layer(model.layers[0], c)
+    # make the trailing norm an identity-free known map: run it separately on the reference's layer output
+    cond = c.cond if adaptive else None
+    past = [(c.past_k, c.past_v)] if adaptive else None
+    # forward_single derives cos/sin from position ids; feed the stored tables instead
+    real = O.rotary_cos_sin
+    O.rotary_cos_sin = lambda inv, pos, dt: (c.cos, c.sin)
+    try:
+        with torch.no_grad():
+            got, _ = model.forward_single(c.h, c.mask, torch.zeros(2, 5, dtype=torch.long), past, False, cond)
+            want, _ = model.norm(c.out, cond)
+    finally:
+        O.rotary_cos_sin = real
+    assert torch.equal(got, want)
+
+
+def test_whole_siglip_encoder_layer():
+    c = g("siglip_layer")
+    layer = O.SiglipEncoderLayer(O.SiglipCfg(hidden_size=48, num_layers=1, num_heads=4, intermediate_size=96)).to(BF)
+    _load_layer(layer, c)
+    with torch.no_grad():
+        assert torch.equal(layer(c.x), c.y)
+
+
+def test_joint_prefix_expert_forward():
+    """PaliGemmaWithExpertModel.forward with both inputs (gemma_pytorch.py:126-279), executed from the reference on a stub
+    `self`: per-expert norms, concatenated-sequence rotary + attention with the 2B layer's scaling, split, o_proj, gated
+    residuals, GeGLU MLPs, final norms — two layers, padded prompt tokens, prefix-LM mask."""
+    c = g("joint")
+    vlm = O.GemmaCfg(width=48, depth=2, mlp_dim=96, num_heads=8, num_kv_heads=1, head_dim=16)
+    exp = O.GemmaCfg(width=32, depth=2, mlp_dim=64, num_heads=8, num_kv_heads=1, head_dim=16)
+    sc = O.SiglipCfg(hidden_size=16, num_layers=1, num_heads=2, intermediate_size=32, patch_size=14, image_size=28, projection_dim=48)
+    model = O.PaliGemmaWithExpertModel(vlm, exp, use_adarms=[False, True], precision="bfloat16", vocab=16, sc=sc)
+    lm, ex = model.paligemma.language_model, model.gemma_expert.model
+    store = {k: v for k, v in vars(c).items() if k.startswith("w__")}
+    for tower, key in ((lm, "vlm"), (ex, "exp")):
+        for i, layer in enumerate(tower.layers):
+            pre = f"w__{key}__{i}__"
+            sd = {k[len(pre):].replace("__", "."): v for k, v in store.items() if k.startswith(pre)}
+            assert set(sd) == {n for n, _ in layer.named_parameters()}
+            for name, p in layer.named_parameters():
+                assert p.dtype == sd[name].dtype, (key, i, name)  # to_bfloat16_for_selected_params chose the same dtypes
+                p.data = sd[name].clone()
+    lm.norm.weight.data = c.vnorm_w.clone()
+    ex.norm.dense.weight.data, ex.norm.dense.bias.data = c.enorm_w.clone(), c.enorm_b.clone()
+    lm.inv_freq = c.inv_freq.clone()  # bf16-rounded, as `.to(bfloat16)` leaves the reference's buffer
+    with torch.no_grad():
+        (po, so), _ = model(c.mask, c.pos, None, [c.x_prefix, c.x_suffix], False, [None, c.cond])
+    assert torch.equal(po, c.prefix_out) and torch.equal(so, c.suffix_out)
+
+
+def test_embed_suffix_pi05_branch():
+    c = g("suffix")
+    cfg = O.OracleConfig(dtype="float32", action_dim=6, action_horizon=5, vocab_size=16, paligemma_variant="dummy",
+                         action_expert_variant="dummy",
+                         siglip=O.SiglipCfg(hidden_size=16, num_layers=1, num_heads=2, intermediate_size=32, image_size=28, projection_dim=64))  # fmt: skip
+    m = O.OraclePI0(cfg)
+    for lin, w, b in ((m.action_in_proj, c.ain_w, c.ain_b), (m.time_mlp_in, c.tin_w, c.tin_b), (m.time_mlp_out, c.tout_w, c.tout_b)):
+        lin.weight.data, lin.bias.data = w.clone(), b.clone()
+    m.action_in_proj.out_features = 32
+    with torch.no_grad():
+        embs, pad, att, cond = m.embed_suffix(c.noisy_actions, c.time)
+    assert torch.allclose(embs, c.embs, atol=1e-6) and torch.allclose(cond, c.cond, atol=1e-6)
+    assert torch.equal(pad, c.pad.bool()) and torch.equal(att.to(c.att.dtype), c.att)
