@@ -16,9 +16,14 @@ transformers 5.x != patched 4.53.2, no jax/flax).  What pins this restatement to
     PI0Pytorch.embed_suffix (pi0.5 branch);
   * the integer/boolean logic additionally against the hand-worked examples of the reference docstring;
   * the state-dict key set against SURVEY.md §8a16.
-**Still unpinned by the reference** (followed line by line, every function cites its lines): the SigLIP patch/position
-embedding and projector, embed_prefix's concatenation, the loss glue of forward() and the Euler loop of sample_actions —
-they need the patched HF model classes to run.
+  * **end to end**: tests/golden/make_reference_e2e_golden.py assembles the WHOLE path from lifted reference code on stub
+    `self` objects (SiglipVisionTransformer, get_image_features, GemmaModel.forward with a KV cache, all three branches of
+    PaliGemmaWithExpertModel.forward, PI0Pytorch.embed_prefix / embed_suffix / forward / denoise_step / sample_actions) and
+    runs it on the tiny test configuration with this oracle's synthetic weights and batch: the reference's loss tensor and
+    10-step action chunk equal this oracle's BIT FOR BIT (tests/golden/reference_e2e.safetensors).
+Restated rather than executed (un-vendored third parties): transformers' DynamicCache.update (append),
+create_causal_mask (4-D pass-through), the default rotary inv_freq, ACT2FN["gelu_pytorch_tanh"]; and observation
+preprocessing, which is the identity for train=False at native resolution.
 
 Module tree and parameter names mirror the reference exactly so a state_dict moves between this oracle and
 the HIP model unchanged:

@@ -1,0 +1,195 @@
+"""End-to-end golden vectors produced by EXECUTING THE REFERENCE'S OWN CODE on the tiny configuration of the parity tests.
+
+Same method as make_reference_blocks_golden.py (definitions lifted out of /root/reference with `ast`, nothing copied), but
+here the whole path is assembled from reference pieces on stub `self` objects:
+  SiglipVisionTransformer (embeddings + encoder + post-LN)  -> PaliGemmaModel.get_image_features + projector
+  GemmaModel.forward (prefix pass with a KV cache; suffix pass against it) over reference GemmaDecoderLayer objects
+  PaliGemmaWithExpertModel.forward (all three branches)
+  PI0Pytorch.embed_prefix / embed_suffix / forward (flow-matching loss) / denoise_step / sample_actions (Euler loop)
+Weights = the oracle's synthetic state dict (identical key names), inputs = the oracle's synthetic batch, so the stored
+loss tensor and action chunk are what THE REFERENCE computes for the very inputs the parity tests use.
+
+Un-vendored third-party behaviour restated here: transformers' DynamicCache (append on the sequence axis),
+create_causal_mask (a 4-D mask passes through), the default rotary inv_freq, ACT2FN["gelu_pytorch_tanh"] (installed copy).
+
+    python tests/golden/make_reference_e2e_golden.py      # build container only; needs /root/reference
+"""
+import functools
+import logging
+import os
+import sys
+import types
+import typing
+
+import torch
+import torch.nn.functional as F
+from safetensors.torch import save_file
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import make_reference_blocks_golden as B  # noqa: E402  (lift / lift_method / base_ns; regenerates the block fixture too)
+from tiny import tiny_cfgs  # noqa: E402
+
+from oracle import pi0_oracle as O  # noqa: E402
+
+REF = B.REF
+BF = torch.bfloat16
+ident = lambda f: f  # noqa: E731
+
+
+class Out:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class StubCache:  # transformers DynamicCache, the two calls the reference makes
+    def __init__(self):
+        self.k, self.v = [], []
+
+    def get_seq_length(self, layer_idx=0):
+        return self.k[0].shape[2] if self.k else 0
+
+    def update(self, k, v, layer_idx, cache_kwargs=None):
+        if layer_idx == len(self.k):
+            self.k.append(k)
+            self.v.append(v)
+        else:
+            self.k[layer_idx] = torch.cat([self.k[layer_idx], k], dim=2)
+            self.v[layer_idx] = torch.cat([self.v[layer_idx], v], dim=2)
+        return self.k[layer_idx], self.v[layer_idx]
+
+    def __getitem__(self, i):
+        return self.k[i], self.v[i]
+
+
+def assign(module, sd, prefix):
+    names = {n for n, _ in module.named_parameters()}
+    got = {k[len(prefix):] for k in sd if k.startswith(prefix)}
+    assert names <= got, (prefix, names - got)
+    for n, p in module.named_parameters():
+        p.data = sd[prefix + n].clone()  # keeps the stored dtype (bf16 weights, f32 selected params)
+
+
+# ---------------------------------------------------------------------------------------------------------------- oracle side
+_, ocfg = tiny_cfgs()
+oracle = O.OraclePI0(ocfg)
+O.synthetic_weights_(oracle, seed=0)
+with torch.no_grad():
+    for n, p in oracle.named_parameters():
+        if p.dim() >= 2:
+            p.mul_(0.08 / 0.02)  # same rescale as tests/tiny.build_pair(std=0.08)
+sd = {k: v.detach().clone() for k, v in oracle.state_dict().items()}
+obs, actions, noise, time = O.synthetic_batch(ocfg, 2, seed=0)
+vlm, exp, sc = O.get_gemma_config("dummy"), O.get_gemma_config("dummy"), ocfg.siglip
+PWE = "paligemma_with_expert."
+
+# ------------------------------------------------------------------------------------------------------------- reference side
+sns = B.base_ns()
+sns.update({"can_return_tuple": ident, "auto_docstring": ident, "BaseModelOutput": Out, "BaseModelOutputWithPooling": Out,
+            "torch_int": int, "SiglipConfig": typing.Any, "PaliGemmaConfig": typing.Any})  # fmt: skip
+B.lift(f"{REF}/transformers_replace/models/siglip/modeling_siglip.py",
+       ["eager_attention_forward", "SiglipAttention", "SiglipMLP", "SiglipEncoderLayer", "SiglipVisionEmbeddings", "SiglipEncoder",
+        "SiglipVisionTransformer"], sns)  # fmt: skip
+scfg = types.SimpleNamespace(hidden_size=sc.hidden_size, num_hidden_layers=sc.num_layers, num_attention_heads=sc.num_heads,
+                             intermediate_size=sc.intermediate_size, patch_size=sc.patch_size, image_size=sc.image_size,
+                             num_channels=3, layer_norm_eps=sc.layer_norm_eps, hidden_act="gelu_pytorch_tanh",
+                             attention_dropout=0.0, _attn_implementation="eager", vision_use_head=False, output_attentions=False,
+                             output_hidden_states=False, projection_dim=sc.projection_dim)  # fmt: skip
+vt = sns["SiglipVisionTransformer"](scfg).eval()
+assign(vt, sd, PWE + "paligemma.model.vision_tower.vision_model.")
+pns = B.base_ns()
+pns.update({"PaliGemmaConfig": typing.Any, "can_return_tuple": ident, "auto_docstring": ident})
+B.lift(f"{REF}/transformers_replace/models/paligemma/modeling_paligemma.py", ["PaliGemmaMultiModalProjector"], pns)
+proj = pns["PaliGemmaMultiModalProjector"](types.SimpleNamespace(vision_config=scfg)).eval()
+assign(proj, sd, PWE + "paligemma.model.multi_modal_projector.")
+get_image_features = B.lift_method(f"{REF}/transformers_replace/models/paligemma/modeling_paligemma.py", "PaliGemmaModel",
+                                   "get_image_features", pns)
+
+gns = B.base_ns()
+gns.update({"dynamic_rope_update": ident, "can_return_tuple": ident, "auto_docstring": ident, "ROPE_INIT_FUNCTIONS": {},
+            "DynamicCache": StubCache,
+            "create_causal_mask": lambda **kw: kw["attention_mask"], "BaseModelOutputWithPast": Out,
+            "logger": logging.getLogger("ref")})  # fmt: skip
+B.lift(f"{REF}/transformers_replace/models/gemma/modeling_gemma.py",
+       ["GemmaRMSNorm", "GemmaMLP", "GemmaRotaryEmbedding", "rotate_half", "apply_rotary_pos_emb", "repeat_kv", "_gated_residual",
+        "eager_attention_forward", "GemmaAttention", "GemmaDecoderLayer"], gns)  # fmt: skip
+gemma_forward = B.lift_method(f"{REF}/transformers_replace/models/gemma/modeling_gemma.py", "GemmaModel", "forward", gns)
+
+
+def gemma_model(cfg, adaptive, prefix, with_embed):
+    c = types.SimpleNamespace(hidden_size=cfg.width, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                              head_dim=cfg.head_dim, attention_bias=False, attention_dropout=0.0, _attn_implementation="eager",
+                              intermediate_size=cfg.mlp_dim, hidden_act="gelu_pytorch_tanh", rms_norm_eps=1e-6,
+                              use_adarms=adaptive, adarms_cond_dim=cfg.width if adaptive else None, num_hidden_layers=cfg.depth,
+                              output_attentions=False, output_hidden_states=False, use_cache=False)  # fmt: skip
+    layers = [gns["GemmaDecoderLayer"](c, i).eval() for i in range(cfg.depth)]
+    for i, layer in enumerate(layers):
+        assign(layer, sd, f"{prefix}layers.{i}.")
+    norm = gns["GemmaRMSNorm"](cfg.width, cond_dim=cfg.width if adaptive else None)
+    assign(norm, sd, prefix + "norm.")
+    Rot = gns["GemmaRotaryEmbedding"]
+    rot = Rot.__new__(Rot)
+    nn.Module.__init__(rot)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.int64).to(torch.float) / cfg.head_dim))
+    rot.register_buffer("inv_freq", inv.to(BF), persistent=False)  # `.to(bfloat16)` on the module rounds the buffer
+    rot.attention_scaling = 1.0
+    m = types.SimpleNamespace(config=c, gradient_checkpointing=False, training=False, layers=layers, norm=norm, rotary_emb=rot,
+                              embed_tokens=None)  # fmt: skip
+    if with_embed:
+        m.embed_tokens = nn.Embedding(ocfg.vocab_size, cfg.width)
+        m.embed_tokens.weight.data = sd[prefix + "embed_tokens.weight"].clone()
+    m.forward = functools.partial(gemma_forward, m)
+    return m
+
+
+lm = gemma_model(vlm, False, PWE + "paligemma.model.language_model.", True)
+ex = gemma_model(exp, True, PWE + "gemma_expert.model.", False)
+
+jns = B.base_ns()
+import pytest  # noqa: E402
+
+jns.update({"pytest": pytest, "modeling_gemma": types.SimpleNamespace(**{k: gns[k] for k in ("apply_rotary_pos_emb", "eager_attention_forward", "_gated_residual")})})
+pwe = types.SimpleNamespace(training=False)
+pwe.paligemma = types.SimpleNamespace(
+    language_model=lm,
+    model=types.SimpleNamespace(language_model=lm, vision_tower=vt, multi_modal_projector=proj),
+    config=types.SimpleNamespace(text_config=types.SimpleNamespace(num_hidden_layers=vlm.depth)))
+pwe.paligemma.model.get_image_features = functools.partial(get_image_features, pwe.paligemma.model)
+pwe.gemma_expert = types.SimpleNamespace(model=ex)
+for name in ("forward", "embed_image", "embed_language_tokens"):
+    setattr(pwe, name, functools.partial(B.lift_method(f"{REF}/gemma_pytorch.py", "PaliGemmaWithExpertModel", name, jns), pwe))
+
+mns = B.base_ns()
+B.lift(f"{REF}/pi0_pytorch.py", ["get_safe_dtype", "create_sinusoidal_pos_embedding", "make_att_2d_masks"], mns)
+pol = types.SimpleNamespace(config=types.SimpleNamespace(action_horizon=ocfg.action_horizon, action_dim=ocfg.action_dim), pi05=True,
+                            gradient_checkpointing_enabled=False, training=False, paligemma_with_expert=pwe)  # fmt: skip
+for head, (i, o) in {"action_in_proj": (ocfg.action_dim, exp.width), "action_out_proj": (exp.width, ocfg.action_dim),
+                     "time_mlp_in": (exp.width, exp.width), "time_mlp_out": (exp.width, exp.width)}.items():
+    lin = nn.Linear(i, o)
+    assign(lin, sd, head + ".")
+    setattr(pol, head, lin)
+for name in ("_apply_checkpoint", "_prepare_attention_masks_4d", "embed_prefix", "embed_suffix", "denoise_step", "forward",
+             "sample_actions"):
+    setattr(pol, name, functools.partial(B.lift_method(f"{REF}/pi0_pytorch.py", "PI0Pytorch", name, mns), pol))
+# preprocessing with train=False on images already at resolution is the identity (preprocessing_pytorch.py:20-173)
+pol._preprocess_observation = lambda o, train=True: (list(o.images.values()), list(o.image_masks.values()), o.tokenized_prompt,
+                                                     o.tokenized_prompt_mask, o.state)  # fmt: skip
+
+with torch.no_grad():
+    ref_loss = pol.forward(obs, actions, noise=noise, time=time)
+    ref_actions = pol.sample_actions(torch.device("cpu"), obs, noise=noise.clone(), num_steps=10)
+    feats = pwe.embed_image(obs.images["base_0_rgb"])
+print("reference loss", tuple(ref_loss.shape), float(ref_loss.mean()), "| actions", tuple(ref_actions.shape), float(ref_actions.abs().mean()))
+with torch.no_grad():
+    o_loss = oracle(obs, actions, noise, time)
+    o_act = oracle.sample_actions(obs, noise.clone(), num_steps=10)
+print("oracle vs reference: loss max|d|", float((o_loss - ref_loss).abs().max()), " actions max|d|", float((o_act - ref_actions).abs().max()))
+save_file({"loss": ref_loss.contiguous(), "actions": ref_actions.contiguous(), "image_features_cam0": feats.contiguous(),
+           "noise": noise.contiguous(), "time": time.contiguous(), "in_actions": actions.contiguous()},
+          os.path.join(HERE, "reference_e2e.safetensors"),
+          metadata={"config": "tests/tiny.tiny_cfgs()", "weights": "oracle.synthetic_weights_(seed=0), matrices x4 (std 0.08)",
+                    "batch": "oracle.synthetic_batch(cfg, 2, seed=0)", "num_steps": "10"})  # fmt: skip
+print("wrote reference_e2e.safetensors")

@@ -117,6 +117,18 @@ def test_sample_actions_matches_oracle_and_golden(pair):
     assert torch.equal(out, out3)
 
 
+def test_against_reference_executed_end_to_end(pair):
+    """HIP loss tensor and action chunk vs tests/golden/reference_e2e.safetensors — the numbers the REFERENCE's own code
+    produces for these weights and inputs (make_reference_e2e_golden.py); same tolerances as against the oracle."""
+    E = load_file(os.path.join(HERE, "golden", "reference_e2e.safetensors"))
+    m, dev = pair["model"], pair["dev"]
+    assert torch.equal(pair["noise"], E["noise"]) and torch.equal(pair["time"], E["time"])
+    loss = m(pair["gobs"], pair["actions"].to(dev), noise=pair["noise"].to(dev), time=pair["time"].to(dev))
+    assert rel(loss, E["loss"]) <= 1e-2
+    out = m.sample_actions(dev, pair["gobs"], noise=pair["noise"].to(dev))
+    assert rel(out, E["actions"]) <= 5e-3 and float((out.float().cpu() - E["actions"]).abs().max()) <= 2e-2
+
+
 def test_padding_does_not_leak(pair):
     """Tokens behind the prompt padding mask must not influence the chunk (mask integer logic end to end)."""
     from tiny import obs_to

@@ -152,3 +152,27 @@ def test_embed_suffix_pi05_branch():
         embs, pad, att, cond = m.embed_suffix(c.noisy_actions, c.time)
     assert torch.allclose(embs, c.embs, atol=1e-6) and torch.allclose(cond, c.cond, atol=1e-6)
     assert torch.equal(pad, c.pad.bool()) and torch.equal(att.to(c.att.dtype), c.att)
+
+
+def test_end_to_end_against_the_reference_assembled_from_its_own_code():
+    """tests/golden/reference_e2e.safetensors: loss tensor and 10-step action chunk computed by the REFERENCE's own code
+    (SigLIP tower, get_image_features, GemmaModel.forward with a KV cache, PaliGemmaWithExpertModel.forward, PI0Pytorch
+    embed_prefix / embed_suffix / forward / denoise_step / sample_actions — lifted and assembled by
+    tests/golden/make_reference_e2e_golden.py) on the tiny configuration, the oracle's synthetic weights and batch.
+    The oracle must reproduce both exactly."""
+    from tiny import tiny_cfgs
+
+    E = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_e2e.safetensors"))
+    _, ocfg = tiny_cfgs()
+    oracle = O.OraclePI0(ocfg)
+    O.synthetic_weights_(oracle, seed=0)
+    with torch.no_grad():
+        for n, p in oracle.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(0.08 / 0.02)
+    obs, actions, noise, time = O.synthetic_batch(ocfg, 2, seed=0)
+    assert torch.equal(noise, E["noise"]) and torch.equal(time, E["time"]) and torch.equal(actions, E["in_actions"])
+    with torch.no_grad():
+        assert torch.equal(oracle(obs, actions, noise, time), E["loss"])
+        assert torch.equal(oracle.sample_actions(obs, noise.clone(), num_steps=10), E["actions"])
+        assert torch.equal(oracle.paligemma_with_expert.embed_image(obs.images["base_0_rgb"]), E["image_features_cam0"])
