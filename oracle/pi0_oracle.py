@@ -19,8 +19,8 @@ transformers 5.x != patched 4.53.2, no jax/flax).  What pins this restatement to
   * **end to end**: tests/golden/make_reference_e2e_golden.py assembles the WHOLE path from lifted reference code on stub
     `self` objects (SiglipVisionTransformer, get_image_features, GemmaModel.forward with a KV cache, all three branches of
     PaliGemmaWithExpertModel.forward, PI0Pytorch.embed_prefix / embed_suffix / forward / denoise_step / sample_actions) and
-    runs it on the tiny test configuration with this oracle's synthetic weights and batch: the reference's loss tensor and
-    10-step action chunk equal this oracle's BIT FOR BIT (tests/golden/reference_e2e.safetensors).
+    runs it on the tiny test configuration with this oracle's synthetic weights and batch: the reference's loss tensor,
+    10-step action chunk and parameter gradients equal this oracle's BIT FOR BIT (tests/golden/reference_e2e.safetensors).
 Restated rather than executed (un-vendored third parties): transformers' DynamicCache.update (append),
 create_causal_mask (4-D pass-through), the default rotary inv_freq, ACT2FN["gelu_pytorch_tanh"]; and observation
 preprocessing, which is the identity for train=False at native resolution.

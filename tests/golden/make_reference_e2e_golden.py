@@ -182,12 +182,40 @@ with torch.no_grad():
     ref_loss = pol.forward(obs, actions, noise=noise, time=time)
     ref_actions = pol.sample_actions(torch.device("cpu"), obs, noise=noise.clone(), num_steps=10)
     feats = pwe.embed_image(obs.images["base_0_rgb"])
+# gradients of mean(loss) through the reference code (autograd over the lifted modules), for a spread of parameters
+GRAD_KEYS = ["action_in_proj.weight", "action_out_proj.bias", "time_mlp_out.weight",
+             PWE + "gemma_expert.model.layers.0.self_attn.q_proj.weight", PWE + "gemma_expert.model.layers.3.input_layernorm.dense.bias",
+             PWE + "gemma_expert.model.norm.dense.weight", PWE + "paligemma.model.language_model.layers.2.mlp.down_proj.weight",
+             PWE + "paligemma.model.language_model.layers.0.input_layernorm.weight",
+             PWE + "paligemma.model.language_model.embed_tokens.weight",
+             PWE + "paligemma.model.vision_tower.vision_model.encoder.layers.1.mlp.fc1.weight",
+             PWE + "paligemma.model.vision_tower.vision_model.embeddings.patch_embedding.weight",
+             PWE + "paligemma.model.multi_modal_projector.linear.bias"]  # fmt: skip
+ref_params = {}
+for prefix, mod in ((PWE + "paligemma.model.vision_tower.vision_model.", vt), (PWE + "paligemma.model.multi_modal_projector.", proj),
+                    ("action_in_proj.", pol.action_in_proj), ("action_out_proj.", pol.action_out_proj),
+                    ("time_mlp_in.", pol.time_mlp_in), ("time_mlp_out.", pol.time_mlp_out)):
+    ref_params.update({prefix + n: p_ for n, p_ in mod.named_parameters()})
+for tower, prefix in ((lm, PWE + "paligemma.model.language_model."), (ex, PWE + "gemma_expert.model.")):
+    for i, layer in enumerate(tower.layers):
+        ref_params.update({f"{prefix}layers.{i}.{n}": p_ for n, p_ in layer.named_parameters()})
+    ref_params.update({prefix + "norm." + n: p_ for n, p_ in tower.norm.named_parameters()})
+ref_params[PWE + "paligemma.model.language_model.embed_tokens.weight"] = lm.embed_tokens.weight
+for p_ in ref_params.values():
+    p_.requires_grad_(True)
+pol.forward(obs, actions, noise=noise, time=time).mean().backward()
+ref_grads = {"grad." + k: ref_params[k].grad.detach().clone() for k in GRAD_KEYS}
+oracle.zero_grad(set_to_none=True)
+oracle(obs, actions, noise, time).mean().backward()
+ograds = dict(oracle.named_parameters())
+print("oracle vs reference gradients: max|d|", max(float((ograds[k].grad - ref_grads["grad." + k]).abs().max()) for k in GRAD_KEYS))
+
 print("reference loss", tuple(ref_loss.shape), float(ref_loss.mean()), "| actions", tuple(ref_actions.shape), float(ref_actions.abs().mean()))
 with torch.no_grad():
     o_loss = oracle(obs, actions, noise, time)
     o_act = oracle.sample_actions(obs, noise.clone(), num_steps=10)
 print("oracle vs reference: loss max|d|", float((o_loss - ref_loss).abs().max()), " actions max|d|", float((o_act - ref_actions).abs().max()))
-save_file({"loss": ref_loss.contiguous(), "actions": ref_actions.contiguous(), "image_features_cam0": feats.contiguous(),
+save_file({**{k: v.contiguous() for k, v in ref_grads.items()}, "loss": ref_loss.contiguous(), "actions": ref_actions.contiguous(), "image_features_cam0": feats.contiguous(),
            "noise": noise.contiguous(), "time": time.contiguous(), "in_actions": actions.contiguous()},
           os.path.join(HERE, "reference_e2e.safetensors"),
           metadata={"config": "tests/tiny.tiny_cfgs()", "weights": "oracle.synthetic_weights_(seed=0), matrices x4 (std 0.08)",

@@ -129,6 +129,23 @@ def test_against_reference_executed_end_to_end(pair):
     assert rel(out, E["actions"]) <= 5e-3 and float((out.float().cpu() - E["actions"]).abs().max()) <= 2e-2
 
 
+def test_gradients_against_reference_executed_backward(pair):
+    """HIP gradients vs the gradients autograd produced THROUGH THE REFERENCE'S OWN CODE (reference_e2e.safetensors);
+    tolerance as for the oracle-autograd comparison (bf16 forward/backward vs bf16 torch ops: rel-L2 <= 5e-2)."""
+    E = load_file(os.path.join(HERE, "golden", "reference_e2e.safetensors"))
+    m, dev = pair["model"], pair["dev"]
+    m.zero_grad(set_to_none=True)
+    m(pair["gobs"], pair["actions"].to(dev), noise=pair["noise"].to(dev), time=pair["time"].to(dev)).mean().backward()
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for k in [k[5:] for k in E if k.startswith("grad.")]:
+        r = rel(params[k].grad, E["grad." + k])
+        worst = max(worst, r)
+        assert r <= 5e-2, (k, r)
+    print("worst gradient rel-L2 vs reference-executed backward:", worst)
+    m.zero_grad(set_to_none=True)
+
+
 def test_padding_does_not_leak(pair):
     """Tokens behind the prompt padding mask must not influence the chunk (mask integer logic end to end)."""
     from tiny import obs_to

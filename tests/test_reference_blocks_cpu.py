@@ -176,3 +176,25 @@ def test_end_to_end_against_the_reference_assembled_from_its_own_code():
         assert torch.equal(oracle(obs, actions, noise, time), E["loss"])
         assert torch.equal(oracle.sample_actions(obs, noise.clone(), num_steps=10), E["actions"])
         assert torch.equal(oracle.paligemma_with_expert.embed_image(obs.images["base_0_rgb"]), E["image_features_cam0"])
+
+
+def test_gradients_against_the_reference_executed_backward():
+    """d mean(loss) / d parameter for a spread of parameters (heads, expert / prefix / SigLIP layers, norms, embeddings),
+    computed by autograd THROUGH THE REFERENCE'S OWN CODE; the oracle's autograd must give the same tensors."""
+    from tiny import tiny_cfgs
+
+    E = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_e2e.safetensors"))
+    keys = [k[5:] for k in E if k.startswith("grad.")]
+    assert len(keys) >= 12
+    _, ocfg = tiny_cfgs()
+    oracle = O.OraclePI0(ocfg)
+    O.synthetic_weights_(oracle, seed=0)
+    with torch.no_grad():
+        for n, p in oracle.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(0.08 / 0.02)
+    obs, actions, noise, time = O.synthetic_batch(ocfg, 2, seed=0)
+    oracle(obs, actions, noise, time).mean().backward()
+    params = dict(oracle.named_parameters())
+    for k in keys:
+        assert torch.equal(params[k].grad, E["grad." + k]), k
