@@ -216,7 +216,9 @@ int kai0_linear_rows_f32(const float* x, const float* W, const float* bias, floa
 int kai0_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int D, float eps,
                      kai0_stream_t stream);
 /* backward kernels take an optional `dres` (bf16 [rows][D]): the gradient arriving at x through its residual branch
- * is added into dx in the same pass (saves a separate add over the activation). */
+ * is added into dx in the same pass (saves a separate add over the activation).
+ * dw_partial: f32 [dw_blocks][D] (LayerNorm: [dwb_blocks][2 D] = dw | db) — one row per block, the block's waves are
+ * reduced in LDS; kai0_reduce_partials sums the rows. */
 int kai0_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, void* dx,
                      float* dw_partial, int dw_blocks, const void* dres, int64_t rows, int D, kai0_stream_t stream);
 int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gate_out, float* rstd, int64_t rows,

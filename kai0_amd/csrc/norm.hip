@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
             }
         }
     }
-    float* pr = dw_partial + wg * D;
+    // the block's 4 wave partials meet in LDS: one partial row per block (a quarter of the bytes the column reduction reads)
+    extern __shared__ float nred[];  // [4][D]
+    float* pr = nred + (threadIdx.x >> 6) * D;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int ci = c * 64 + lane;
@@ -222,6 +224,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
             *reinterpret_cast<f32x4*>(pr + ci * 8 + 4) = f32x4{dwa[c][4], dwa[c][5], dwa[c][6], dwa[c][7]};
         }
     }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256)
+        dw_partial[(int64_t)blockIdx.x * D + col] = (nred[col] + nred[D + col]) + (nred[2 * D + col] + nred[3 * D + col]);
 }
 
 // adaRMS backward: one block per batch entry b (rows b*rpb .. b*rpb+rpb-1), thread owns 8 columns.
@@ -398,7 +403,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
             }
         }
     }
-    float* pr = partial + wg * (int64_t)(2 * D);
+    extern __shared__ float nred[];  // [4][2 D]: the block's wave partials -> one partial row per block
+    float* pr = nred + (threadIdx.x >> 6) * (2 * D);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int ci = c * 64 + lane;
@@ -410,6 +416,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
             }
         }
     }
+    __syncthreads();
+    const int W = 2 * D;
+    for (int col = threadIdx.x; col < W; col += 256)
+        partial[(int64_t)blockIdx.x * W + col] = (nred[col] + nred[W + col]) + (nred[2 * W + col] + nred[3 * W + col]);
 }
 
 // ------------------------------------------------------------------------------------ column reductions
@@ -476,7 +486,7 @@ KAI0_API int kai0_rmsnorm_bwd(const void* dy, const void* x, const float* w, con
                               kai0_stream_t stream) {
     CHECK_D("kai0_rmsnorm_bwd", D);
     KAI0_REQUIRE(dw_blocks > 0, "kai0_rmsnorm_bwd: dw_blocks must be > 0");
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(dw_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(dw_blocks), dim3(256), 4 * D * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, w, rstd, (bf16_t*)dx, dw_partial, (const bf16_t*)dres, rows, D);
     return kai0_check_launch("kai0_rmsnorm_bwd");
 }
@@ -530,7 +540,7 @@ KAI0_API int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, co
                                 kai0_stream_t stream) {
     CHECK_D("kai0_layernorm_bwd", D);
     KAI0_REQUIRE(dwb_blocks > 0, "kai0_layernorm_bwd: dwb_blocks must be > 0");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(dwb_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(dwb_blocks), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dwb_partial, (const bf16_t*)dres, rows, D);
     return kai0_check_launch("kai0_layernorm_bwd");
 }

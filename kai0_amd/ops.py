@@ -481,13 +481,13 @@ class RMSNormFn(torch.autograd.Function):
         dres = dres.contiguous() if dres is not None else None
         dx = torch.empty_like(x)
         nb = NORM_PARTIAL_BLOCKS
-        part = torch.empty((nb * 4, D), dtype=F32, device=x.device)
+        part = torch.empty((nb, D), dtype=F32, device=x.device)  # one partial row per block
         _lib.call("kai0_rmsnorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
                   part.data_ptr(), nb, _p(dres), rows, D, _stream())  # fmt: skip
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _grad_dst(w, F32)
-            _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, D, D, dw.data_ptr(), 1, _stream())
+            _lib.call("kai0_reduce_partials", part.data_ptr(), nb, D, D, dw.data_ptr(), 1, _stream())
         return dx, _grad_ret(w, dw), None
 
 
@@ -570,13 +570,13 @@ class LayerNormFn(torch.autograd.Function):
         rows, D = x.shape
         dx = torch.empty_like(x)
         nb = NORM_PARTIAL_BLOCKS
-        part = torch.empty((nb * 4, 2 * D), dtype=F32, device=x.device)
+        part = torch.empty((nb, 2 * D), dtype=F32, device=x.device)  # one partial row per block
         _lib.call("kai0_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                   dx.data_ptr(), part.data_ptr(), nb, _p(dres), rows, D, _stream())  # fmt: skip
         dw, db = _grad_dst(w, w.dtype), _grad_dst(b, b.dtype)
         f32 = int(w.dtype == F32)
-        _lib.call("kai0_reduce_partials", part.data_ptr(), nb * 4, D, 2 * D, dw.data_ptr(), f32, _stream())
-        _lib.call("kai0_reduce_partials", part.data_ptr() + 4 * D, nb * 4, D, 2 * D, db.data_ptr(), f32, _stream())
+        _lib.call("kai0_reduce_partials", part.data_ptr(), nb, D, 2 * D, dw.data_ptr(), f32, _stream())
+        _lib.call("kai0_reduce_partials", part.data_ptr() + 4 * D, nb, D, 2 * D, db.data_ptr(), f32, _stream())
         return dx, _grad_ret(w, dw), _grad_ret(b, db), None
 
 
