@@ -926,8 +926,12 @@ class JointAttentionFn(torch.autograd.Function):
         Bn = qs[0].shape[0] // seg_lens[0]
         S_ld = round_up(S, 8)
         q_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-        k_all = torch.zeros((Bn, S_ld, HD), dtype=BF16, device=dev)
-        v_all = torch.zeros((Bn, S_ld, HD), dtype=BF16, device=dev)
+        k_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
+        v_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
+        if S_ld > S:  # only the padding rows need defined (zero) contents: they enter dK/dV GEMMs multiplied by P = 0
+            q_all[:, S:].zero_()
+            k_all[:, S:].zero_()
+            v_all[:, S:].zero_()
         r0 = 0
         for i in range(nseg):
             Li = seg_lens[i]
@@ -957,7 +961,9 @@ class JointAttentionFn(torch.autograd.Function):
         Bn, S, S_ld, H, HD, seg_lens, scale = ctx.cfg
         dev = q_all.device
         M = S * H
-        datt = torch.zeros((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        datt = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        if S_ld > S:
+            datt[:, S:].zero_()
         r0 = 0
         for i, Li in enumerate(seg_lens):
             _copy_rows(douts[i].contiguous(), datt, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
