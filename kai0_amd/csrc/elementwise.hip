@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
 
 // ------------------------------------------------------------------------------------- masked softmax
 constexpr int SM_MAXC = 8;  // ld <= 4096
+// NCH = 16-B chunks per lane (ld <= NCH * 512): instantiated for 1, 2, 4, 8 so that a 1024-wide row keeps 16 values in
+// registers, not 64 (the single 8-chunk version needed 255 VGPRs -> 2 waves/SIMD and ran at 1.8 TB/s)
+template <int NCH>
 __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* scores, bf16_t* probs,
                                                                const int32_t* __restrict__ qcode,
                                                                const int32_t* __restrict__ kcode, int B, int Sq, int H,
@@ -90,10 +93,10 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* sco
         const int qc = qcode ? qcode[(int64_t)b * qld + s] : INT_MAX;
         const bf16_t* sp = scores + (int64_t)b * bstride + rr * ld;
         bf16_t* pp = probs + (int64_t)b * bstride + rr * ld;
-        float v[SM_MAXC][8];
+        float v[NCH][8];
         float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < SM_MAXC; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
                 ld8(sp + ci * 8, v[c]);
@@ -124,12 +127,13 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* sco
         float sum = 0.f;
         if (m > -INFINITY) {
 #pragma unroll
-            for (int c = 0; c < SM_MAXC; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 const int ci = c * 64 + lane;
                 if (ci < nchunk) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        v[c][e] = expf(v[c][e] - m);  // exp(-inf) = 0 for masked columns
+                        v[c][e] = __expf(v[c][e] - m);  // exp(-inf) = 0 for masked columns; v_exp_f32 path (as attn_fwd):
+                                                        // libm expf made this kernel VALU-bound at 1.8 TB/s
                         sum += v[c][e];
                     }
                 }
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void softmax_mask_fwd_kernel(const bf16_t* sco
         sum = wave_sum(sum);
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
 #pragma unroll
-        for (int c = 0; c < SM_MAXC; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
                 float o[8];
@@ -547,9 +551,15 @@ KAI0_API int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_
     KAI0_REQUIRE((qcode == nullptr) == (kcode == nullptr), "kai0_softmax_mask_fwd: qcode/kcode must both be set");
     const int64_t rows = (int64_t)B * Sq * H;
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_mask_fwd_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream),
-                       (const bf16_t*)scores, (bf16_t*)probs, qcode, kcode, B, Sq, H, Sk, ld, batch_stride, q0,
-                       qcode_ld, kcode_ld);
+#define KAI0_SM_LAUNCH(N)                                                                                          \
+    hipLaunchKernelGGL(softmax_mask_fwd_kernel<N>, dim3(ew_grid(rows, 4)), dim3(256), 0, S_(stream),              \
+                       (const bf16_t*)scores, (bf16_t*)probs, qcode, kcode, B, Sq, H, Sk, ld, batch_stride, q0,    \
+                       qcode_ld, kcode_ld)
+    if (ld <= 512) KAI0_SM_LAUNCH(1);
+    else if (ld <= 1024) KAI0_SM_LAUNCH(2);
+    else if (ld <= 2048) KAI0_SM_LAUNCH(4);
+    else KAI0_SM_LAUNCH(8);
+#undef KAI0_SM_LAUNCH
     return kai0_check_launch("kai0_softmax_mask_fwd");
 }
 
