@@ -72,3 +72,12 @@ class Pi0Config:
             self.max_token_len = 200 if self.pi05 else 48
         if self.discrete_state_input is None:
             self.discrete_state_input = self.pi05
+
+
+@dataclasses.dataclass
+class AdvantageEstimatorConfig(Pi0Config):
+    """`openpi.models.pi0_config.AdvantageEstimatorConfig` (pi0_config.py:138-142): the two loss weights of the
+    Stage-Advantage estimator (training/config.py:1225-1226 trains it with value 1 / action 0)."""
+
+    loss_action_weight: float = 1.0
+    loss_value_weight: float = 1.0

@@ -481,17 +481,16 @@ class PI0Pytorch(nn.Module):
         return a.view(B, Hs, De), pad, att, cond
 
     # ---- training forward ---------------------------------------------------------------------------------
-    def forward(self, observation, actions, noise=None, time=None) -> torch.Tensor:
-        """pi0_pytorch.py:316-373 -> un-reduced flow-matching loss f32 [B, H, A]."""
-        images, img_masks, lang_tokens, lang_masks, state = self._preprocess_observation(
-            observation, train=self.train_augmentation
-        )
-        if noise is None:
-            noise = self.sample_noise(actions.shape, actions.device)
-        if time is None:
-            time = self.sample_time(actions.shape[0], actions.device)
-        actions = actions.to(F32).contiguous()
-        x_t, u_t = ops.flow_mix(noise.to(F32).contiguous(), actions, time.to(F32).contiguous())
+    def _trunk(self, images, img_masks, lang_tokens, lang_masks, state, actions, noise, time, x_t=None):
+        """Everything of the training forward up to the expert's output: -> (u_t f32 [B*H, A], suffix_out f32 [B*H, De],
+        v_t f32 [B*H, A]) with suffix_out already through the final adaRMS norm (pi0_pytorch.py:326-368).  With `x_t`
+        given the flow-matching mix is skipped (u_t = None): the suffix is embedded from x_t as is."""
+        u_t = None
+        if x_t is None:
+            actions = actions.to(F32).contiguous()
+            x_t, u_t = ops.flow_mix(noise.to(F32).contiguous(), actions, time.to(F32).contiguous())
+        else:
+            x_t = x_t.to(F32).contiguous()
         prefix, ppad, patt = self.embed_prefix(images, img_masks, lang_tokens, lang_masks)
         suffix, spad, satt, cond = self.embed_suffix(state, x_t, time)
         B, P, Dp = prefix.shape
@@ -501,8 +500,20 @@ class PI0Pytorch(nn.Module):
         out = self.paligemma_with_expert.forward_joint(prefix.reshape(B * P, Dp), suffix_bf, qcode, kcode, pos, cond, B, P, Hs)
         out32 = ops.cast_ag(out, F32)
         v_t = ops.linear_f32(out32, self.action_out_proj.weight, self.action_out_proj.bias)
-        loss = ops.mse_loss(u_t.view(B * Hs, -1), v_t)
-        return loss.view(B, Hs, -1)
+        return (u_t.view(B * Hs, -1) if u_t is not None else None), out32, v_t
+
+    def forward(self, observation, actions, noise=None, time=None) -> torch.Tensor:
+        """pi0_pytorch.py:316-373 -> un-reduced flow-matching loss f32 [B, H, A]."""
+        images, img_masks, lang_tokens, lang_masks, state = self._preprocess_observation(
+            observation, train=self.train_augmentation
+        )
+        if noise is None:
+            noise = self.sample_noise(actions.shape, actions.device)
+        if time is None:
+            time = self.sample_time(actions.shape[0], actions.device)
+        B, Hs = actions.shape[0], actions.shape[1]
+        u_t, _, v_t = self._trunk(images, img_masks, lang_tokens, lang_masks, state, actions, noise, time)
+        return ops.mse_loss(u_t, v_t).view(B, Hs, -1)
 
     # ---- inference ----------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -517,6 +528,71 @@ class PI0Pytorch(nn.Module):
         if self._engine is None or not self._engine.compatible(bsize, lang_tokens.shape[1], len(images)):
             self._engine = InferenceEngine(self, bsize, lang_tokens.shape[1], len(images))
         return self._engine.sample_actions(images, img_masks, lang_tokens, lang_masks, noise.to(F32), num_steps)
+
+
+class AdvantageEstimator(PI0Pytorch):
+    """The advantage / progress estimator of Stage-Advantage (pi0_pytorch.py:464-644): the pi0.5 trunk plus a value head
+    (Linear-SiLU-Linear-SiLU-Linear-Tanh, f32) on the first suffix token's final representation.
+      forward      -> loss [B, H] = loss_action_weight * mean_d mse(u_t, v_t) + loss_value_weight * mse(value, clamp(progress, +-1))
+      sample_values-> value [B, 1] from one joint forward with sampled (or given) noise / time
+    State-dict keys follow nn.Sequential numbering: value_head.{0,2,4}.{weight,bias}.  Observations may carry up to six
+    images (two timesteps x three cameras, ordered (timestep, base < left_wrist < right_wrist)); no augmentation
+    (preprocess_observation_pytorch_custom(..., apply_aug=False))."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.loss_value_weight = getattr(config, "loss_value_weight", 0.0)
+        self.loss_action_weight = getattr(config, "loss_action_weight", 1.0)
+        w = self.action_in_proj.out_features
+        self.value_head = nn.Sequential(Linear(w, w), nn.Identity(), Linear(w, w), nn.Identity(), Linear(w, 1), nn.Identity())
+
+    def _preprocess_observation(self, observation, *, train=True, return_full_obs=False):
+        from .preprocessing import preprocess_observation_custom
+
+        res = self.paligemma_with_expert.siglip_cfg.image_size
+        obs = preprocess_observation_custom(observation, train=train, image_resolution=(res, res), apply_aug=False)
+        full = (list(obs.images.values()), list(obs.image_masks.values()), obs.tokenized_prompt, obs.tokenized_prompt_mask,
+                obs.state, obs)  # fmt: skip
+        return full if return_full_obs else full[:-1]
+
+    def _value(self, out32, B: int, Hs: int):
+        vh = self.value_head
+        deep = out32.view(B, Hs, -1)[:, 0, :].contiguous()  # first suffix token, f32
+        x = ops.silu_f32(ops.linear_f32(deep, vh[0].weight, vh[0].bias))
+        x = ops.silu_f32(ops.linear_f32(x, vh[2].weight, vh[2].bias))
+        return torch.tanh(ops.linear_f32(x, vh[4].weight, vh[4].bias))  # [B, 1]
+
+    def forward(self, observation, actions, noise=None, time=None, return_loss_dict=False):
+        images, img_masks, lang_tokens, lang_masks, state, obs_full = self._preprocess_observation(
+            observation, train=self.training, return_full_obs=True
+        )
+        if noise is None:
+            noise = self.sample_noise(actions.shape, actions.device)
+        if time is None:
+            time = self.sample_time(actions.shape[0], actions.device)
+        B, Hs = actions.shape[0], actions.shape[1]
+        u_t, out32, v_t = self._trunk(images, img_masks, lang_tokens, lang_masks, state, actions, noise, time)
+        loss_action = ops.mse_loss(u_t, v_t).view(B, Hs, -1).mean(dim=-1)  # [B, H]
+        loss = loss_action * self.loss_action_weight
+        value = self._value(out32, B, Hs)
+        target = torch.clamp(obs_full.progress.float(), -1.0, 1.0).unsqueeze(1)
+        value_loss = (value - target) ** 2 * self.loss_value_weight  # [B, 1]
+        aux = {"loss_action": loss_action.detach().mean(), "loss_value": value_loss.detach().mean()}
+        loss = loss + value_loss
+        return (loss, aux) if return_loss_dict else loss
+
+    @torch.no_grad()
+    def sample_values(self, device, observation, noise=None, time=None) -> torch.Tensor:
+        """pi0_pytorch.py:596-644.  `noise` / `time` may be injected (the reference samples them)."""
+        images, img_masks, lang_tokens, lang_masks, state = self._preprocess_observation(observation, train=False)
+        B = state.shape[0]
+        Hs = self.config.action_horizon
+        if noise is None:
+            noise = self.sample_noise((B, Hs, self.config.action_dim), device)
+        if time is None:
+            time = self.sample_time(B, device)
+        _, out32, _ = self._trunk(images, img_masks, lang_tokens, lang_masks, state, None, None, time, x_t=noise)
+        return self._value(out32, B, Hs)
 
 
 class PrefixAssembleFn(torch.autograd.Function):

@@ -167,3 +167,21 @@ def preprocess_observation(observation, *, train: bool = False, image_keys: Sequ
         token_ar_mask=getattr(observation, "token_ar_mask", None),
         token_loss_mask=getattr(observation, "token_loss_mask", None),
     )
+
+
+def preprocess_observation_custom(observation, *, train: bool = False, image_resolution: tuple[int, int] | None = None,
+                                  apply_aug: bool = True):  # fmt: skip
+    """preprocessing_pytorch.py:175-330: like preprocess_observation, but over WHATEVER images the observation carries
+    (keys `<part>_<timestep>_rgb`), ordered by (timestep, base < left_wrist < right_wrist), augmentation only if
+    `train and apply_aug`; keeps the extra fields (progress, ...) of the observation."""
+    order = {"base": 0, "left_wrist": 1, "right_wrist": 2}
+
+    def sort_key(k):
+        part, timestep, _ = k.rsplit("_", 2)
+        return int(timestep), order[part]
+
+    keys = sorted(observation.images.keys(), key=sort_key)
+    out = preprocess_observation(observation, train=train and apply_aug, image_keys=keys, image_resolution=image_resolution)
+    for name in ("progress", "episode_index", "frame_index", "episode_length", "image_original"):
+        setattr(out, name, getattr(observation, name, None))
+    return out

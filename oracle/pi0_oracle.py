@@ -611,6 +611,61 @@ class OraclePI0(nn.Module):  # pi0_pytorch.py:84-461 (pi05=True branch only; tra
 
 
 # ------------------------------------------------------------------------------------ synthetic data / weights
+class OracleAdvantageEstimator(OraclePI0):  # pi0_pytorch.py:464-644
+    def __init__(self, config: OracleConfig, loss_value_weight: float = 0.0, loss_action_weight: float = 1.0):
+        super().__init__(config)
+        self.loss_value_weight, self.loss_action_weight = loss_value_weight, loss_action_weight
+        w = get_gemma_config(config.action_expert_variant).width
+        self.value_head = nn.Sequential(nn.Linear(w, w), nn.SiLU(), nn.Linear(w, w), nn.SiLU(), nn.Linear(w, 1), nn.Tanh())  # :471-481
+
+    @staticmethod
+    def _unpack_sorted(obs):  # preprocessing_pytorch.py:193-202 (apply_aug=False, native resolution => identity otherwise)
+        order = {"base": 0, "left_wrist": 1, "right_wrist": 2}
+
+        def key(k):
+            part, ts, _ = k.rsplit("_", 2)
+            return int(ts), order[part]
+
+        keys = sorted(obs.images.keys(), key=key)
+        b = obs.state.shape[:-1]
+        masks = [obs.image_masks[k] if k in obs.image_masks else torch.ones(b, dtype=torch.bool) for k in keys]
+        return [obs.images[k] for k in keys], masks, obs.tokenized_prompt, obs.tokenized_prompt_mask
+
+    def _suffix_out(self, observation, x_t, time):  # the shared middle of forward (:515-552) and sample_values (:610-636)
+        images, img_masks, lang_tokens, lang_masks = self._unpack_sorted(observation)
+        prefix_embs, prefix_pad, prefix_att = self.embed_prefix(images, img_masks, lang_tokens, lang_masks)
+        suffix_embs, suffix_pad, suffix_att, adarms_cond = self.embed_suffix(x_t, time)
+        if self._is_bf16():
+            suffix_embs, prefix_embs = suffix_embs.to(torch.bfloat16), prefix_embs.to(torch.bfloat16)
+        pad = torch.cat([prefix_pad, suffix_pad], dim=1)
+        att = torch.cat([prefix_att, suffix_att], dim=1)
+        att_2d = make_att_2d_masks(pad, att)
+        position_ids = torch.cumsum(pad, dim=1) - 1
+        (_, suffix_out), _ = self.paligemma_with_expert(masks_4d(att_2d), position_ids, None, [prefix_embs, suffix_embs], False,
+                                                        [None, adarms_cond])  # fmt: skip
+        return suffix_out
+
+    def forward(self, observation, actions, noise, time, return_loss_dict=False):  # :500-592
+        te = time[:, None, None]
+        x_t = te * noise + (1 - te) * actions
+        u_t = noise - actions
+        suffix_out_full = self._suffix_out(observation, x_t, time)
+        v_t = self.action_out_proj(suffix_out_full[:, -self.config.action_horizon :].to(dtype=torch.float32))
+        loss_action = F.mse_loss(u_t, v_t, reduction="none").mean(dim=-1)  # :563
+        loss = loss_action * self.loss_action_weight
+        value_pred = self.value_head(suffix_out_full[:, 0, :].to(dtype=torch.float32))  # :571-572
+        target = torch.clamp(observation.progress.float(), -1.0, 1.0).unsqueeze(1)  # :574-576
+        value_loss = F.mse_loss(value_pred, target, reduction="none").to(loss.dtype) * self.loss_value_weight
+        aux = {"loss_action": loss_action.detach().mean(), "loss_value": value_loss.detach().mean()}
+        loss = loss + value_loss
+        return (loss, aux) if return_loss_dict else loss
+
+    @torch.no_grad()
+    def sample_values(self, observation, noise, time):  # :596-644 with the sampled noise / time injected
+        suffix_out = self._suffix_out(observation, noise, time)
+        return self.value_head(suffix_out[:, 0, :].to(dtype=torch.float32))
+
+
 class SimpleObs:
     def __init__(self, **kw):
         for k, v in kw.items():

@@ -210,12 +210,62 @@ oracle(obs, actions, noise, time).mean().backward()
 ograds = dict(oracle.named_parameters())
 print("oracle vs reference gradients: max|d|", max(float((ograds[k].grad - ref_grads["grad." + k]).abs().max()) for k in GRAD_KEYS))
 
+# ---- AdvantageEstimator (pi0_pytorch.py:464-644): forward with progress targets and sample_values, six images -----------
+#      (two timesteps x three cameras, deliberately inserted out of order), executed on the same stub with the class's own
+#      forward / sample_values lifted; preprocessing (apply_aug=False, native resolution) is the reference's key sort.
+AE = {}
+torch.manual_seed(99)
+vh = nn.Sequential(nn.Linear(exp.width, exp.width), nn.SiLU(), nn.Linear(exp.width, exp.width), nn.SiLU(), nn.Linear(exp.width, 1), nn.Tanh())
+for p_ in vh.parameters():
+    p_.data = torch.randn(p_.shape) * 0.06
+    p_.requires_grad_(False)
+g6 = torch.Generator().manual_seed(6)
+extra = {k: torch.rand(2, 3, sc.image_size, sc.image_size, generator=g6) * 2 - 1 for k in ("right_wrist_-1_rgb", "base_-1_rgb", "left_wrist_-1_rgb")}
+ims6 = {"left_wrist_0_rgb": obs.images["left_wrist_0_rgb"], **extra, "base_0_rgb": obs.images["base_0_rgb"],
+        "right_wrist_0_rgb": obs.images["right_wrist_0_rgb"]}
+progress = torch.tensor([0.35, -1.7])
+obs6 = types.SimpleNamespace(images=ims6, image_masks={k: torch.ones(2, dtype=torch.bool) for k in ims6}, state=obs.state,
+                             tokenized_prompt=obs.tokenized_prompt, tokenized_prompt_mask=obs.tokenized_prompt_mask,
+                             token_ar_mask=None, token_loss_mask=None, progress=progress, frame_index=None, episode_length=None,
+                             image_original=None, episode_index=None)  # fmt: skip
+cns = B.base_ns()
+cns.update({"image_tools": types.SimpleNamespace(resize_with_pad_torch=None), "logger": logging.getLogger("ref"),
+            "Sequence": __import__("collections.abc").abc.Sequence, "IMAGE_RESOLUTION": (sc.image_size, sc.image_size)})
+B.lift("/root/reference/src/openpi/models_pytorch/preprocessing_pytorch.py", ["preprocess_observation_pytorch_custom"], cns)
+ans = B.base_ns()
+ans.update({k: mns[k] for k in ("create_sinusoidal_pos_embedding", "make_att_2d_masks")})
+ans["_preprocessing"] = types.SimpleNamespace(preprocess_observation_pytorch_custom=functools.partial(
+    cns["preprocess_observation_pytorch_custom"], image_resolution=(sc.image_size, sc.image_size)))
+est = types.SimpleNamespace(**pol.__dict__)
+est.value_head, est.loss_value_weight, est.loss_action_weight, est.training = vh, 0.7, 1.3, False
+for name in ("_apply_checkpoint", "_prepare_attention_masks_4d", "embed_prefix", "embed_suffix"):
+    setattr(est, name, functools.partial(B.lift_method(f"{REF}/pi0_pytorch.py", "PI0Pytorch", name, ans), est))
+for name in ("_preprocess_observation", "forward", "sample_values"):
+    setattr(est, name, functools.partial(B.lift_method(f"{REF}/pi0_pytorch.py", "AdvantageEstimator", name, ans), est))
+sv_noise = torch.randn(2, ocfg.action_horizon, ocfg.action_dim, generator=g6)
+sv_time = torch.tensor([0.62, 0.11])
+est.sample_noise = lambda shape, device: sv_noise.clone()
+est.sample_time = lambda bsize, device: sv_time.clone()
+with torch.no_grad():
+    ae_loss, ae_aux = est.forward(obs6, actions, noise=noise, time=time, return_loss_dict=True)
+    ae_values = est.sample_values(torch.device("cpu"), obs6)
+oest = O.OracleAdvantageEstimator(ocfg, loss_value_weight=0.7, loss_action_weight=1.3)
+oest.load_state_dict({**sd, **{"value_head." + k: v for k, v in vh.state_dict().items()}}, strict=True)
+with torch.no_grad():
+    o_loss6, o_aux = oest(obs6, actions, noise, time, return_loss_dict=True)
+    o_val = oest.sample_values(obs6, sv_noise, sv_time)
+print("advantage estimator, oracle vs reference: loss max|d|", float((o_loss6 - ae_loss).abs().max()), " values max|d|",
+      float((o_val - ae_values).abs().max()), "| values", ae_values.flatten().tolist())
+AE.update({"ae.loss": ae_loss, "ae.values": ae_values, "ae.loss_action": ae_aux["loss_action"].reshape(1),
+           "ae.loss_value": ae_aux["loss_value"].reshape(1), "ae.progress": progress, "ae.sv_noise": sv_noise, "ae.sv_time": sv_time,
+           **{"ae.img." + k: v for k, v in extra.items()}, **{"ae.value_head." + k: v for k, v in vh.state_dict().items()}})
+
 print("reference loss", tuple(ref_loss.shape), float(ref_loss.mean()), "| actions", tuple(ref_actions.shape), float(ref_actions.abs().mean()))
 with torch.no_grad():
     o_loss = oracle(obs, actions, noise, time)
     o_act = oracle.sample_actions(obs, noise.clone(), num_steps=10)
 print("oracle vs reference: loss max|d|", float((o_loss - ref_loss).abs().max()), " actions max|d|", float((o_act - ref_actions).abs().max()))
-save_file({**{k: v.contiguous() for k, v in ref_grads.items()}, "loss": ref_loss.contiguous(), "actions": ref_actions.contiguous(), "image_features_cam0": feats.contiguous(),
+save_file({**{k: v.contiguous() for k, v in ref_grads.items()}, **{k: v.contiguous() for k, v in AE.items()}, "loss": ref_loss.contiguous(), "actions": ref_actions.contiguous(), "image_features_cam0": feats.contiguous(),
            "noise": noise.contiguous(), "time": time.contiguous(), "in_actions": actions.contiguous()},
           os.path.join(HERE, "reference_e2e.safetensors"),
           metadata={"config": "tests/tiny.tiny_cfgs()", "weights": "oracle.synthetic_weights_(seed=0), matrices x4 (std 0.08)",

@@ -6,6 +6,7 @@ ours: vs the bf16-choreography oracle rel-L2 <= 1e-2 on the loss tensor and <= 5
 (tests/test_host_cpu.py)."""
 
 import copy
+import dataclasses
 import os
 
 import pytest
@@ -241,3 +242,51 @@ def test_state_dict_roundtrip_bit_exact(pair, tmp_path):
     load_model(m2, path)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert a.dtype == b.dtype and torch.equal(a, b), k
+
+
+def test_advantage_estimator_against_reference_executed():
+    """kai0_amd.model.AdvantageEstimator (value head + weighted loss, six images sorted by (timestep, camera)) vs the numbers
+    the reference's own AdvantageEstimator.forward / sample_values produce (reference_e2e.safetensors, `ae.*`), and the
+    gradient of the value head vs the oracle's autograd.  Tolerances: loss rel-L2 <= 1e-2 as for the policy loss; the value
+    is tanh of a 3-layer f32 MLP on a bf16 trunk output: |d| <= 5e-3."""
+    from tiny import estimator_case, obs_to, tiny_cfgs
+
+    from kai0_amd.config import AdvantageEstimatorConfig
+    from kai0_amd.model import AdvantageEstimator
+
+    E = load_file(os.path.join(HERE, "golden", "reference_e2e.safetensors"))
+    oest, obs6, actions, noise, time = estimator_case(E)
+    dev = torch.device("cuda:0")
+    pcfg, _ = tiny_cfgs()
+    m = AdvantageEstimator(AdvantageEstimatorConfig(**dataclasses.asdict(pcfg) | {"siglip": pcfg.siglip}, loss_value_weight=0.7,
+                                                    loss_action_weight=1.3))  # fmt: skip
+    m.load_state_dict(oest.state_dict(), strict=True)
+    m = m.to(dev)
+    g6 = obs_to(obs6, dev)
+    g6.progress = obs6.progress.to(dev)
+    m.eval()
+    loss, aux = m(g6, actions.to(dev), noise=noise.to(dev), time=time.to(dev), return_loss_dict=True)
+    assert loss.shape == (2, 10) and loss.dtype == torch.float32
+    r = rel(loss.detach(), E["ae.loss"])
+    print(f"estimator loss rel-L2 vs reference: {r:.3e}; loss_action {float(aux['loss_action']):.5f} vs {float(E['ae.loss_action']):.5f};"
+          f" loss_value {float(aux['loss_value']):.5f} vs {float(E['ae.loss_value']):.5f}")  # fmt: skip
+    assert r <= 1e-2
+    assert abs(float(aux["loss_action"]) - float(E["ae.loss_action"])) <= 1e-2 * float(E["ae.loss_action"])
+    assert abs(float(aux["loss_value"]) - float(E["ae.loss_value"])) <= 2e-2 * float(E["ae.loss_value"])
+    values = m.sample_values(dev, g6, noise=E["ae.sv_noise"].to(dev), time=E["ae.sv_time"].to(dev))
+    assert values.shape == (2, 1)
+    d = float((values.cpu() - E["ae.values"]).abs().max())
+    print("estimator values", values.flatten().tolist(), "reference", E["ae.values"].flatten().tolist())
+    assert d <= 5e-3
+    # backward: value-head and trunk gradients vs the fp32 oracle's autograd
+    m.zero_grad(set_to_none=True)
+    loss.mean().backward()
+    o32 = copy.deepcopy(oest)
+    o32.paligemma_with_expert.to_bfloat16_for_selected_params("float32")
+    o32(obs6, actions, noise, time).mean().backward()
+    po, pm = dict(o32.named_parameters()), dict(m.named_parameters())
+    for k in ("value_head.0.weight", "value_head.2.bias", "value_head.4.weight", "action_out_proj.weight",
+              "paligemma_with_expert.gemma_expert.model.layers.1.mlp.down_proj.weight",
+              "paligemma_with_expert.paligemma.model.language_model.layers.1.self_attn.q_proj.weight"):
+        rg = rel(pm[k].grad, po[k].grad)
+        assert rg <= 5e-2, (k, rg)

@@ -198,3 +198,22 @@ def test_gradients_against_the_reference_executed_backward():
     params = dict(oracle.named_parameters())
     for k in keys:
         assert torch.equal(params[k].grad, E["grad." + k]), k
+
+
+def test_advantage_estimator_against_the_reference_executed():
+    """AdvantageEstimator.forward (action loss * w_a + (value - clamp(progress))^2 * w_v, pi0_pytorch.py:500-592) and
+    sample_values (:596-644), executed from the reference's own source on six out-of-order images with the reference's
+    preprocess_observation_pytorch_custom doing the (timestep, camera) sort; the oracle must reproduce loss, the two
+    logged scalars and the values exactly."""
+    from tiny import estimator_case
+
+    E = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_e2e.safetensors"))
+    est, obs6, actions, noise, time = estimator_case(E)
+    with torch.no_grad():
+        loss, aux = est(obs6, actions, noise, time, return_loss_dict=True)
+        values = est.sample_values(obs6, E["ae.sv_noise"], E["ae.sv_time"])
+    assert loss.shape == (2, 10) and values.shape == (2, 1)
+    assert torch.equal(loss, E["ae.loss"]) and torch.equal(values, E["ae.values"])
+    assert torch.equal(aux["loss_action"].reshape(1), E["ae.loss_action"])
+    assert torch.equal(aux["loss_value"].reshape(1), E["ae.loss_value"])
+    assert float(values.abs().max()) < 0.9  # the tanh is not saturated, so the value head's numerics are really compared

@@ -42,3 +42,29 @@ def obs_to(obs, device):
         state=obs.state.to(device), tokenized_prompt=obs.tokenized_prompt.to(device),
         tokenized_prompt_mask=obs.tokenized_prompt_mask.to(device), token_ar_mask=None, token_loss_mask=None,
     )
+
+
+def estimator_case(E):
+    """The AdvantageEstimator case of tests/golden/reference_e2e.safetensors (make_reference_e2e_golden.py): the tiny model's
+    weights + a seeded value head, six images (two timesteps x three cameras) inserted out of (timestep, camera) order,
+    progress targets (one outside [-1, 1]).  Returns (oracle_estimator, observation, actions, noise, time)."""
+    from oracle.pi0_oracle import OracleAdvantageEstimator, OraclePI0, SimpleObs, synthetic_batch, synthetic_weights_
+
+    _, ocfg = tiny_cfgs()
+    base = OraclePI0(ocfg)
+    synthetic_weights_(base, seed=0)
+    with torch.no_grad():
+        for n, p in base.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(0.08 / 0.02)
+    est = OracleAdvantageEstimator(ocfg, loss_value_weight=0.7, loss_action_weight=1.3)
+    est.load_state_dict({**base.state_dict(), **{k[3:]: v for k, v in E.items() if k.startswith("ae.value_head.")}}, strict=True)
+    obs, actions, noise, time = synthetic_batch(ocfg, 2, seed=0)
+    extra = {k[7:]: v for k, v in E.items() if k.startswith("ae.img.")}
+    images = {"left_wrist_0_rgb": obs.images["left_wrist_0_rgb"], "right_wrist_-1_rgb": extra["right_wrist_-1_rgb"],
+              "base_-1_rgb": extra["base_-1_rgb"], "left_wrist_-1_rgb": extra["left_wrist_-1_rgb"],
+              "base_0_rgb": obs.images["base_0_rgb"], "right_wrist_0_rgb": obs.images["right_wrist_0_rgb"]}  # fmt: skip
+    obs6 = SimpleObs(images=images, image_masks={k: torch.ones(2, dtype=torch.bool) for k in images}, state=obs.state,
+                     tokenized_prompt=obs.tokenized_prompt, tokenized_prompt_mask=obs.tokenized_prompt_mask, token_ar_mask=None,
+                     token_loss_mask=None, progress=E["ae.progress"])  # fmt: skip
+    return est, obs6, actions, noise, time
