@@ -285,6 +285,12 @@ def main():
             # algorithmic flops of a launch = 2 M N K of that launch (no tile padding counted); summed over the launches
             # of the measured steps and divided by their summed HIP-event durations
             achieved = gemm_flops / 1e12 / (gemm_ms / 1e3)
+            # PMC counters cannot be read from inside this process: the per-launch HBM-side bytes come from the committed
+            # rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh -> profiles/gemm_traffic.json)
+            traffic = {}
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gemm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath))
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": "gemm_bf16_kernel (NT/NN/TN variants; every Linear, attention matmul, dgrad and wgrad)",
@@ -292,7 +298,9 @@ def main():
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic.get("bytes_per_launch"),
+                "traffic_unit": "HBM-side bytes per GEMM launch (fetch + write), rocprofv3 PMC; not re-measured by this run",
+                "traffic_source": traffic.get("source"),
                 "launches_per_step": n_launch // timer_steps,
                 "avg_launch_ms": gemm_ms / n_launch,
                 "gemm_ms_per_step": gemm_ms / timer_steps,

@@ -63,6 +63,29 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
     float right = 0.5f * x * (1.0f - t * t) * kBeta * (1.0f + 3.0f * kKappa * x2);
     return left + right;
 }
+// Two values at a time on the packed-f32 VALU (v_pk_mul_f32 / v_pk_add_f32: one instruction per two lanes' worth of
+// elements); only the exponential and the reciprocal stay scalar (quarter rate).  The fused GeGLU epilogues are VALU-bound
+// (a 256x256 tile is 128 elements per thread with nothing else running on the CU), so instruction count is their time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 rbf2(f32x2 x) { return f32x2{rbf(x[0]), rbf(x[1])}; }
+__device__ __forceinline__ f32x2 fast_tanh2(f32x2 x) {
+    const f32x2 x2 = x * 2.0f;
+    const f32x2 d = f32x2{__expf(x2[0]), __expf(x2[1])} + 1.0f;
+    return 1.0f - f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])} * 2.0f;
+}
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+    const f32x2 inner = (x + x * x * x * 0.044715f) * 0.7978845608028654f;
+    return x * 0.5f * (fast_tanh2(inner) + 1.0f);
+}
+// value and derivative from one tanh
+__device__ __forceinline__ void gelu_tanh_both2(f32x2 x, f32x2& val, f32x2& grad) {
+    const f32x2 xx = x * x;
+    const f32x2 inner = (x + x * xx * 0.044715f) * 0.7978845608028654f;
+    const f32x2 t = fast_tanh2(inner);
+    const f32x2 half1pt = (t + 1.0f) * 0.5f;
+    val = x * half1pt;
+    grad = half1pt + x * (1.0f - t * t) * (xx * (3.0f * 0.044715f) + 1.0f) * (0.5f * 0.7978845608028654f);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // ---- wave64 reductions -----------------------------------------------------------------------

@@ -131,7 +131,11 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
             *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = R(gelu_tanh_f(v[e]));
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 a = gelu_tanh2(f32x2{v[e], v[e + 1]});
+            v[e] = R(a[0]);
+            v[e + 1] = R(a[1]);
+        }
     } else if (p.act == 2) {
         // GeGLU forward fused into the up-projection GEMM: v = u; pre_out <- u; C <- bf16(bf16(gelu(g)) * u)
         if (p.pre_out != nullptr) {  // u is only needed by the backward
@@ -142,7 +146,11 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         }
         const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.aux1 + cz + orow * p.ldc + ccol);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = R(R(gelu_tanh_f(bf2f(gv[e]))) * v[e]);
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 a = gelu_tanh2(f32x2{bf2f(gv[e]), bf2f(gv[e + 1])});
+            v[e] = R(R(a[0]) * v[e]);
+            v[e + 1] = R(R(a[1]) * v[e + 1]);
+        }
     } else if (p.act == 3) {
         // GeGLU backward fused into the down-projection dgrad: v = dh; pre_out <- du = bf16(dh * bf16(gelu(g)));
         // C <- dg = bf16(bf16(dh * u) * gelu'(g))
@@ -150,10 +158,13 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         const bf16x8 uv = *reinterpret_cast<const bf16x8*>(p.aux2 + cz + orow * p.ldc + ccol);
         bf16x8 du;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float gg = bf2f(gv[e]);
-            du[e] = f2bf(v[e] * R(gelu_tanh_f(gg)));
-            v[e] = R(R(v[e] * bf2f(uv[e])) * gelu_tanh_grad_f(gg));
+        for (int e = 0; e < 8; e += 2) {
+            f32x2 gl, gr;
+            gelu_tanh_both2(f32x2{bf2f(gv[e]), bf2f(gv[e + 1])}, gl, gr);
+            du[e] = f2bf(v[e] * R(gl[0]));
+            du[e + 1] = f2bf(v[e + 1] * R(gl[1]));
+            v[e] = R(R(v[e] * bf2f(uv[e])) * gr[0]);
+            v[e + 1] = R(R(v[e + 1] * bf2f(uv[e + 1])) * gr[1]);
         }
         *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = du;
     }
@@ -553,8 +564,88 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const bool col_ok = ccol < ((p.N + 7) & ~7);
     // one 64-row half of the wave's sub-tile at a time; `h` is a compile-time constant so acc[] keeps static indices
     // (a rolled loop here would turn the accumulators into an indexed array for the whole kernel)
+    // Fused GeGLU / softmax-backward epilogues read one or two more [M][N] operands.  In the rolled loop below every
+    // iteration would wait out a full global-load latency (16 per tile, +24 us on a 62-us tile); the fast path issues the
+    // 8 (x2) operand loads of a 64-row half before the accumulators even go to the slab and consumes them unrolled.
+    const bool fused_fast = p.act >= 2 && p.split_k == 1 && p.bias == nullptr && p.gate == nullptr && p.residual == nullptr &&
+                            !p.accumulate && !p.out_f32 && p.nseg == 0 && (p.act == 4 || p.scale == 1.0f) &&
+                            (p.act != 3 || p.pre_out != nullptr);
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
+        if (fused_fast) {
+            bf16x8 s0[8], s1[8];
+            float ds[8];
+            const int rbase = m0 + wm * (MT * 16) + h * 64 + (lane >> 3);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + it * 8;
+                s0[it] = bf16x8{};
+                s1[it] = bf16x8{};
+                ds[it] = 0.f;
+                if (row < p.M && col_ok) {
+                    const int64_t o = cz + p.cmap(row) * p.ldc + ccol;
+                    s0[it] = *reinterpret_cast<const bf16x8*>(p.aux1 + o);
+                    if (p.act == 3) s1[it] = *reinterpret_cast<const bf16x8*>(p.aux2 + o);
+                    if (p.act == 4) ds[it] = p.rowvec[vz + (int64_t)row * p.rv_ld];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            bf16_t* cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + it * 8;
+                const float* sp = slab + (it * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (row >= p.M || !col_ok) continue;
+                const int64_t o = cz + p.cmap(row) * p.ldc + ccol;
+                bf16x8 ov;
+                if (p.act == 2) {  // same order and rounding points as epilogue8
+                    if (p.pre_out != nullptr) {
+                        bf16x8 uv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) uv[e] = f2bf(v[e]);
+                        *reinterpret_cast<bf16x8*>(p.pre_out + o) = uv;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 r = rbf2(gelu_tanh2(f32x2{bf2f(s0[it][e]), bf2f(s0[it][e + 1])})) * rbf2(f32x2{v[e], v[e + 1]});
+                        ov[e] = f2bf(r[0]);
+                        ov[e + 1] = f2bf(r[1]);
+                    }
+                } else if (p.act == 3) {
+                    bf16x8 du;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 dh = rbf2(f32x2{v[e], v[e + 1]});
+                        f32x2 gl, gr;
+                        gelu_tanh_both2(f32x2{bf2f(s0[it][e]), bf2f(s0[it][e + 1])}, gl, gr);
+                        const f32x2 a = dh * rbf2(gl);
+                        const f32x2 b = rbf2(dh * f32x2{bf2f(s1[it][e]), bf2f(s1[it][e + 1])}) * gr;
+                        du[e] = f2bf(a[0]);
+                        du[e + 1] = f2bf(a[1]);
+                        ov[e] = f2bf(b[0]);
+                        ov[e + 1] = f2bf(b[1]);
+                    }
+                    *reinterpret_cast<bf16x8*>(p.pre_out + o) = du;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = f2bf((bf2f(s0[it][e]) * (v[e] - ds[it])) * p.scale);
+                }
+                *reinterpret_cast<bf16x8*>(cb + o) = ov;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -16,5 +16,6 @@ for C in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
   timeout 900 rocprofv3 --pmc $CN --kernel-trace -d /tmp/pmc_$DN -o p --output-format csv -- $ONE > $OUT/pmc_$DN.log 2>&1
   python tools/pmc_summary.py /tmp/pmc_$DN 14 > $OUT/pmc_$DN.txt 2>&1
 done
+python tools/gemm_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/gemm_traffic.json > $OUT/gemm_traffic.log 2>&1
 grep -h '"metric"' $OUT/*.log | cut -c1-600
 ls -la $OUT
