@@ -1,0 +1,99 @@
+"""`Policy.infer` — the request handler around `sample_actions` (SURVEY.md §8b "Policy", §8 f2;
+`src/openpi/policies/policy.py:25-122`, factory `policy_config.py:16-94`, interface
+`packages/openpi-client/src/openpi_client/base_policy.py:5-12`).
+
+One call = copy the observation dict -> input transforms (repack, default prompt, robot transform, normalise, resize,
+tokenise, pad) -> add the batch axis and move to the device -> `Observation.from_dict` -> `model.sample_actions(device,
+observation, noise=...)` -> first batch entry back to numpy -> output transforms (unnormalise, robot transform) ->
+`policy_timing.infer_ms` (model time only, as the reference reports it).  Single in-flight request per Policy: the model's
+static buffers and hipGraph are not re-entrant (SURVEY.md §8b "Threading")."""
+
+from __future__ import annotations
+
+import abc
+import time
+from collections.abc import Mapping, Sequence
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import transforms as _transforms
+from .preprocessing import Observation
+
+
+class BasePolicy(abc.ABC):
+    @abc.abstractmethod
+    def infer(self, obs: dict) -> dict:
+        """Infer actions from observations."""
+
+    def reset(self) -> None:
+        pass
+
+
+def _map_leaves(fn, tree):
+    if isinstance(tree, Mapping):
+        return {k: _map_leaves(fn, v) for k, v in tree.items()}
+    return fn(tree)
+
+
+class Policy(BasePolicy):
+    def __init__(self, model, *, transforms: Sequence = (), output_transforms: Sequence = (),
+                 sample_kwargs: dict[str, Any] | None = None, metadata: dict[str, Any] | None = None,
+                 pytorch_device: str = "cuda:0", is_pytorch: bool = True, rng=None):  # fmt: skip
+        if not is_pytorch:
+            raise ValueError("kai0_amd.policy.Policy serves the torch-protocol model only (JAX checkpoints: convert first)")
+        self._model = model.to(pytorch_device)
+        self._model.eval()
+        self._input_transform = _transforms.compose(transforms)
+        self._output_transform = _transforms.compose(output_transforms)
+        self._sample_kwargs = sample_kwargs or {}
+        self._metadata = metadata or {}
+        self._pytorch_device = pytorch_device
+        self._sample_actions = self._model.sample_actions
+
+    def infer(self, obs: dict, *, noise: np.ndarray | None = None) -> dict:
+        dev = self._pytorch_device
+        inputs = _map_leaves(lambda x: x, obs)  # shallow structural copy: transforms may rebind entries
+        inputs = self._input_transform(inputs)
+        inputs = _map_leaves(lambda x: torch.from_numpy(np.array(x)).to(dev)[None, ...], inputs)
+        kwargs = dict(self._sample_kwargs)
+        if noise is not None:
+            n = torch.from_numpy(noise).to(dev)
+            kwargs["noise"] = n[None, ...] if n.ndim == 2 else n
+        observation = Observation.from_dict(inputs)
+        t0 = time.monotonic()
+        outputs = {"state": inputs["state"], "actions": self._sample_actions(dev, observation, **kwargs)}
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize()  # sample_actions returns as soon as the graph is launched
+        model_time = time.monotonic() - t0
+        outputs = _map_leaves(lambda x: np.asarray(x[0, ...].detach().cpu()), outputs)
+        outputs = self._output_transform(outputs)
+        outputs["policy_timing"] = {"infer_ms": model_time * 1000}
+        return outputs
+
+    @property
+    def metadata(self) -> dict[str, Any]:
+        return self._metadata
+
+
+def create_policy(model, *, norm_stats: Mapping | None, tokenizer, action_dim: int = 32, use_quantile_norm: bool = True,
+                  discrete_state_input: bool = True, image_size: int = 224, robot_inputs: Sequence = (),
+                  robot_outputs: Sequence = (), repack_transforms: _transforms.Group | None = None,
+                  default_prompt: str | None = None, sample_kwargs: dict | None = None, metadata: dict | None = None,
+                  pytorch_device: str = "cuda:0") -> Policy:  # fmt: skip
+    """The transform stack of `create_trained_policy` (policy_config.py:75-94) with the pi0.5 model transforms of
+    `ModelTransformFactory` (training/config.py:129-141), assembled from explicit pieces instead of a TrainConfig:
+      inputs : repack -> default prompt -> robot inputs -> Normalize -> [default prompt, ResizeImages, TokenizePrompt,
+               PadStatesAndActions]
+      outputs: Unnormalize -> robot outputs -> repack outputs."""
+    repack = repack_transforms or _transforms.Group()
+    return Policy(
+        model,
+        transforms=[*repack.inputs, _transforms.InjectDefaultPrompt(default_prompt), *robot_inputs,
+                    _transforms.Normalize(norm_stats, use_quantiles=use_quantile_norm),
+                    _transforms.InjectDefaultPrompt(default_prompt), _transforms.ResizeImages(image_size, image_size),
+                    _transforms.TokenizePrompt(tokenizer, discrete_state_input=discrete_state_input),
+                    _transforms.PadStatesAndActions(action_dim)],
+        output_transforms=[_transforms.Unnormalize(norm_stats, use_quantiles=use_quantile_norm), *robot_outputs, *repack.outputs],
+        sample_kwargs=sample_kwargs, metadata=metadata, pytorch_device=pytorch_device)  # fmt: skip
