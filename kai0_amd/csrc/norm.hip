@@ -443,22 +443,45 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     }
 }
 
+// Column sums of a [M][N] bf16 matrix (bias gradients): block (x, y) covers the 512 columns [512 x, 512 x + 512) — one wave
+// is 64 lanes x 8 columns = 1 KiB of a row — and the rows y*4 + w, stepping by 4*gridDim.y; each wave keeps 4 independent
+// row loads in flight, the 4 waves' sums meet in LDS, and the block writes one partial row for reduce_partials.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int64_t M, int N, int64_t ld,
                                                      float* __restrict__ scratch) {
-    const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc * 8 >= N) return;
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 8;
+    const bool live = col < N;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
-        float v[8];
-        load8(dy + m * ld + cc * 8, v);
+    const int64_t step = (int64_t)gridDim.y * 4;
+    int64_t m = (int64_t)blockIdx.y * 4 + wave;
+    if (live) {
+        for (; m + 3 * step < M; m += 4 * step) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8(dy + m * ld + col, v0);
+            load8(dy + (m + step) * ld + col, v1);
+            load8(dy + (m + 2 * step) * ld + col, v2);
+            load8(dy + (m + 3 * step) * ld + col, v3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        }
+        for (; m < M; m += step) {
+            float v[8];
+            load8(dy + m * ld + col, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
     }
-    float* sp = scratch + (int64_t)blockIdx.y * N + cc * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sp[e] = acc[e];
+    for (int e = 0; e < 8; ++e) red[wave][lane][e] = acc[e];
+    __syncthreads();
+    if (wave == 0 && live) {
+        float* sp = scratch + (int64_t)blockIdx.y * N + col;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sp[e] = (red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e]);
+    }
 }
 
 inline int norm_grid(int64_t rows) {
@@ -559,7 +582,8 @@ KAI0_API int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, floa
     KAI0_REQUIRE(scratch_blocks > 0, "kai0_colsum_bf16: scratch_blocks must be > 0");
     int sb = scratch_blocks;
     if ((int64_t)sb > M) sb = (int)M;
-    dim3 grid((N / 8 + 255) / 256, sb, 1);
+    if ((int64_t)sb * 4 > M) sb = (int)((M + 3) / 4);
+    dim3 grid((N / 8 + 63) / 64, sb, 1);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, M, N, ld, scratch);
     int rc = kai0_check_launch("kai0_colsum_bf16");
     if (rc) return rc;
