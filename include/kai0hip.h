@@ -264,13 +264,15 @@ int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode,
                           int64_t qcode_ld, int64_t kcode_ld, kai0_stream_t stream);
 /* Backward of SigLIP's unmasked multi-head attention for one layer, one block per (image, head)
  * (modeling_siglip.py:325-345 through autograd; S = 256 tokens, head_dim = 72 — the so400m/14 @ 224 tower):
- *   q, k, v, dO, O, dq, dk, dv : bf16 [n_img*S][NH*HD] (head h at column h*HD);  P : bf16 [n_img*NH][S][ldp] from kai0_attn_fwd
+ *   q, k, v, dO, O : bf16 [n_img*S][NH*HD] (head h at column h*HD);  P : bf16 [n_img*NH][S][ldp] from kai0_attn_fwd
+ *   dq, dk, dv : bf16 rows of stride ld_grad (0 = NH*HD; 3*NH*HD when the three are the column slices of one [rows][3*NH*HD]
+ *                buffer, which lets the fused q|k|v projection backward read them as a single operand)
  *   D = rowsum(dO * O);  dS = bf16((P * (dO V^T - D)) * scale)  (dP in f32, never stored);
  *   dQ = bf16(dS K), dK = bf16(dS^T Q), dV = bf16(P^T dO).  Same rounding points as the GEMM formulation
  *   (kai0_gemm_bf16 act 4 + three batched GEMMs) it replaces. */
 int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void* dO, const void* O, const void* P,
-                         void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD, int64_t ldp, float scale,
-                         kai0_stream_t stream);
+                         void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD, int64_t ldp, int64_t ld_grad,
+                         float scale, kai0_stream_t stream);
 /* out[r] = sum_d a[r][d] * b[r][d] in f32 (rows of D contiguous bf16 elements, D % 8 == 0): the softmax-backward row term */
 int kai0_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int D, kai0_stream_t stream);
 /* dscores = bf16( (probs * (dprobs - sum_j dprobs*probs)) * scale ).  dprobs is bf16 or (dprobs_f32) f32:

@@ -31,7 +31,8 @@ struct SbArgs {
     const bf16_t *q, *k, *v, *dO, *O, *P;
     bf16_t *dq, *dk, *dv;
     int NH;
-    int64_t E;
+    int64_t E;   // row stride (elements) of q / k / v / dO / O: NH * 72
+    int64_t Eg;  // row stride of dq / dk / dv (>= E: the three may be column slices of one [rows][3 E] buffer)
     float scale;
     int dbg;  // diagnostics (KAI0_SB_DBG): 1 = stop after staging + D, 2 = stop after phase A, 3 = skip phase A
 };
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
     const bf16_t* vg = p.v + base;
     const bf16_t* dOg = p.dO + base;
     const bf16_t* Og = p.O + base;
+    const int64_t gbase = (int64_t)n * SB_S * p.Eg + (int64_t)h * SB_HD;  // the same row / head in the gradient buffers
     const bf16_t* Pg = p.P + (int64_t)bh * SB_S * SB_S;
 
     // ---- D[q] = sum_d dO[q][d] * O[q][d] ---------------------------------------------------------------
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
                 accq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_trfrag(T0, SB_LDR, kb, 16 * dt, l15, g), ds, accq[dt], 0, 0, 0);
         }
         // accq[dt]: lane (q = q0 + l15, g) holds d = 16 dt + 4 g + r
-        bf16_t* dqp = p.dq + base + (int64_t)(q0 + l15) * p.E;
+        bf16_t* dqp = p.dq + gbase + (int64_t)(q0 + l15) * p.Eg;
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt) {
             const int d0 = 16 * dt + 4 * g;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-        const int64_t ro = base + (int64_t)(32 * wave + 16 * kt + l15) * p.E;
+        const int64_t ro = gbase + (int64_t)(32 * wave + 16 * kt + l15) * p.Eg;
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt) {
             const int d0 = 16 * dt + 4 * g;
@@ -266,11 +268,13 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
 
 KAI0_API int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void* dO, const void* O,
                                   const void* P, void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD,
-                                  int64_t ldp, float scale, kai0_stream_t stream) {
+                                  int64_t ldp, int64_t ld_grad, float scale, kai0_stream_t stream) {
     KAI0_REQUIRE(q && k && v && dO && O && P && dq && dk && dv, "kai0_siglip_attn_bwd: null operand");
     KAI0_REQUIRE(S == SB_S && HD == SB_HD && ldp == SB_S,
                  "kai0_siglip_attn_bwd: built for S = 256, head_dim = 72, ldp = 256 (got S=%d HD=%d ldp=%lld)", S, HD, (long long)ldp);
     KAI0_REQUIRE(NH >= 1, "kai0_siglip_attn_bwd: NH");
+    if (ld_grad == 0) ld_grad = (int64_t)NH * HD;
+    KAI0_REQUIRE(ld_grad >= (int64_t)NH * HD && ld_grad % 4 == 0, "kai0_siglip_attn_bwd: ld_grad=%lld", (long long)ld_grad);
     if (n_img <= 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -279,7 +283,7 @@ KAI0_API int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, c
         attr_set = true;
     }
     SbArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)P,
-             (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, NH, (int64_t)NH * HD, scale, 0};
+             (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, NH, (int64_t)NH * HD, ld_grad, scale, 0};
     static const int dbg = [] { const char* e = getenv("KAI0_SB_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     hipLaunchKernelGGL(siglip_attn_bwd_kernel, dim3(n_img * NH), dim3(512), SB_LDS, (hipStream_t)stream, a);

@@ -356,23 +356,120 @@ def linear(x, w, bias=None, residual=None, act=0):
     return LinearFn.apply(x, w, bias, residual, act)
 
 
+def fused_columns(rows: int, widths, device):
+    """Column slices [rows, w_i] of one fresh bf16 [rows, sum(w)] buffer.  A backward that hands these to autograd lets
+    LinearMultiFn recognise them (`_as_fused`) and run its dgrad / wgrad on the whole buffer without a concatenation."""
+    buf = torch.empty((rows, sum(widths)), dtype=BF16, device=device)
+    out, c = [], 0
+    for w in widths:
+        out.append(buf[:, c : c + w])
+        c += w
+    return out
+
+
+def _as_fused(ts, widths):
+    """The [rows, sum(widths)] tensor whose column slices `ts` are (in order), or None."""
+    t0 = ts[0]
+    if t0 is None or t0.dim() != 2:
+        return None
+    total = sum(widths)
+    off = t0.storage_offset()
+    for t, w in zip(ts, widths):
+        if (t is None or t.dtype != t0.dtype or t.dim() != 2 or t.shape != (t0.shape[0], w) or t.stride() != (total, 1)
+                or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr() or t.storage_offset() != off):  # fmt: skip
+            return None
+        off += w
+    return t0.as_strided((t0.shape[0], total), (total, 1), t0.storage_offset())
+
+
+_FUSE_MULTI = os.environ.get("KAI0_FUSE_QKV", "1") != "0"
+
+
 class LinearMultiFn(torch.autograd.Function):
-    """Several Linears of the same input (q/k/v projections): y_i = x W_i^T (+ b_i).  One autograd node, so the input
-    gradient is produced by accumulating the dgrads in the GEMM epilogue instead of separate add passes."""
+    """Several Linears of the same input (q/k/v projections): y_i = x W_i^T (+ b_i), as ONE GEMM over the stacked weight
+    [sum N_i, K] whose epilogue routes the column ranges to the separate outputs; the backward is one dgrad (K = sum N_i)
+    and one wgrad over the stacked dY.  The weights stay separate parameters (state-dict contract): stacking them is a
+    copy of the weights only (MBs per layer against GEMMs of GFLOPs), and so is splitting the stacked gradient."""
 
     @staticmethod
     def forward(ctx, x, n: int, *wb):
         _chk(x, BF16, "linear_multi.x")
         ws, bs = wb[:n], wb[n:]
-        outs = tuple(linear_fwd(x, w, b) for w, b in zip(ws, bs))
-        ctx.save_for_backward(x, *ws)
-        ctx.biases = bs
-        ctx.n = n
+        widths = tuple(int(w.shape[0]) for w in ws)
+        has_b = [b is not None for b in bs]
+        fuse = (_FUSE_MULTI and 2 <= n <= 3 and all(w % 8 == 0 for w in widths) and (all(has_b) or not any(has_b))
+                and (not any(has_b) or len({b.dtype for b in bs}) == 1))  # fmt: skip
+        ctx.n, ctx.biases, ctx.widths, ctx.fuse = n, bs, widths, fuse
+        if not fuse:
+            outs = tuple(linear_fwd(x, w, b) for w, b in zip(ws, bs))
+            ctx.save_for_backward(x, *ws)
+            return outs
+        M, K = x.shape
+        Nt = sum(widths)
+        wcat = torch.cat(ws, dim=0)
+        bcat = torch.cat(bs, dim=0) if all(has_b) else None
+        outs = tuple(torch.empty((M, w), dtype=BF16, device=x.device) for w in widths)
+        segs, c = [], 0
+        for o, w in zip(outs, widths):
+            segs.append((o, w, c))
+            c += w
+        gemm(x, wcat, outs[0], M=M, N=Nt, K=K, lda=K, ldb=K, ldc=widths[0], bias=bcat, segs=segs, split_k=pick_split_k(M, Nt, K))
+        ctx.save_for_backward(x, wcat, *ws)
         return outs
 
     @staticmethod
     def backward(ctx, *douts):
-        x, *ws = ctx.saved_tensors
+        n, bs, widths = ctx.n, ctx.biases, ctx.widths
+        if not ctx.fuse or any(d is None for d in douts):
+            x, *rest = ctx.saved_tensors
+            ws = rest[1:] if ctx.fuse else rest
+            return LinearMultiFn._backward_separate(ctx, x, ws, douts)
+        x, wcat, *ws = ctx.saved_tensors
+        M, K = x.shape
+        Nt = sum(widths)
+        dev = x.device
+        dy = _as_fused(douts, widths)
+        if dy is None:
+            dy = torch.cat([d if d.dtype == BF16 else d.to(BF16) for d in douts], dim=1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=BF16, device=dev)
+            if M >= 4096:
+                wt = transpose(wcat)  # [K, Nt]: K-contiguous operand for the fast NT schedule
+                gemm(dy, wt, dx, M=M, N=K, K=Nt, lda=Nt, ldb=Nt, ldc=K)
+                del wt
+            else:
+                gemm(dy, wcat, dx, M=M, N=K, K=Nt, a_kc=True, b_kc=False, lda=Nt, ldb=K, ldc=K)
+        dws, dbs = [None] * n, [None] * n
+        if any(ctx.needs_input_grad[2 + i] for i in range(n)):
+            dsts = [_grad_dst(w, BF16) for w in ws]
+            dwcat = _as_rows(dsts)
+            tmp = dwcat is None
+            if tmp:
+                dwcat = torch.empty((Nt, K), dtype=BF16, device=dev)
+            gemm(dy, x, dwcat, M=Nt, N=K, K=M, a_kc=False, b_kc=False, lda=Nt, ldb=K, ldc=K, split_k=pick_split_k(Nt, K, M))
+            r = 0
+            for i, (w, dst) in enumerate(zip(ws, dsts)):
+                if tmp:
+                    dst.copy_(dwcat[r : r + widths[i]])
+                r += widths[i]
+                dws[i] = _grad_ret(w, dst)
+        if bs[0] is not None and any(ctx.needs_input_grad[2 + n + i] for i in range(n)):
+            f32 = bs[0].dtype == F32
+            dbcat = torch.empty((Nt,), dtype=bs[0].dtype, device=dev)
+            scratch = torch.empty((COLSUM_BLOCKS, Nt), dtype=F32, device=dev)
+            _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, Nt, Nt, scratch.data_ptr(), COLSUM_BLOCKS, dbcat.data_ptr(), int(f32),
+                      _stream())  # fmt: skip
+            r = 0
+            for i, b in enumerate(bs):
+                db = _grad_dst(b, b.dtype)
+                db.copy_(dbcat[r : r + widths[i]])
+                r += widths[i]
+                dbs[i] = _grad_ret(b, db)
+        return (dx, None, *dws, *dbs)
+
+    @staticmethod
+    def _backward_separate(ctx, x, ws, douts):
         n, bs = ctx.n, ctx.biases
         M, K = x.shape
         dev = x.device
@@ -405,6 +502,18 @@ class LinearMultiFn(torch.autograd.Function):
         if dx is not None and first:
             dx.zero_()
         return (dx, None, *dws, *dbs)
+
+
+def _as_rows(ts):
+    """The [sum rows, K] tensor made of the contiguous 2-D tensors `ts` if they lie back to back in one storage, or None."""
+    t0 = ts[0]
+    ptr = t0.data_ptr()
+    for t in ts:
+        if (not t.is_contiguous() or t.dtype != t0.dtype or t.shape[1:] != t0.shape[1:] or t.data_ptr() != ptr
+                or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr()):  # fmt: skip
+            return None
+        ptr += t.numel() * t.element_size()
+    return t0.as_strided((sum(t.shape[0] for t in ts), *t0.shape[1:]), t0.stride(), t0.storage_offset())
 
 
 def linear_multi(x, weights, biases=None):
@@ -992,12 +1101,11 @@ class JointAttentionFn(torch.autograd.Function):
         grads = []
         r0 = 0
         for Li in seg_lens:
-            dq = torch.empty((Bn * Li, H * HD), dtype=BF16, device=dev)
-            dk = torch.empty((Bn * Li, HD), dtype=BF16, device=dev)
-            dv = torch.empty((Bn * Li, HD), dtype=BF16, device=dev)
-            _copy_rows(dq_all, dq, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * H * HD, 0, H * HD)
-            _copy_rows(dk_all, dk, Bn, Li, HD, S_ld * HD, r0, HD, Li * HD, 0, HD)
-            _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * HD, 0, HD)
+            W3 = (H + 2) * HD  # dq | dk | dv as column slices of one [Bn*Li, W3] buffer (see fused_columns)
+            dq, dk, dv = fused_columns(Bn * Li, (H * HD, HD, HD), dev)
+            _copy_rows(dq_all, dq, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * W3, 0, W3)
+            _copy_rows(dk_all, dk, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
+            _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
             grads += [dq, dk, dv]
             r0 += Li
         return (None, None, None, None, None, None, None, *grads)
@@ -1036,9 +1144,11 @@ class SiglipAttentionFn(torch.autograd.Function):
         dout = dout.contiguous()
         if S == 256 and HD == 72 and S_ld == 256 and _SIGLIP_BWD_FUSED:
             # the real tower (so400m/14 @ 224): one block per (image, head) runs the whole backward out of LDS
-            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            # dq | dk | dv are the column slices of one buffer: the fused q|k|v projection backward reads it whole
+            dq, dk, dv = fused_columns(q.shape[0], (E, E, E), dev)
             _lib.call("kai0_siglip_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), out.data_ptr(),
-                      probs.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), n_img, S, NH, HD, S_ld, scale, _stream())  # fmt: skip
+                      probs.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), n_img, S, NH, HD, S_ld, 3 * E, scale,
+                      _stream())  # fmt: skip
             return dq, dk, dv, None, None, None, None
         nb = n_img * NH
         sP = (NH * S * S_ld, S * S_ld)
