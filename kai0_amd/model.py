@@ -310,8 +310,8 @@ class PaliGemmaWithExpertModel(nn.Module):
             a = ops.siglip_attention(q, k, v, n, S, NH, HD)
             x = _lin(a, at.out_proj, residual=x)
             x, h = ops.layernorm_res(x, layer.layer_norm2.weight, layer.layer_norm2.bias, layer.layer_norm2.eps)
-            f = _lin(h, layer.mlp.fc1, act=1)
-            return _lin(f, layer.mlp.fc2, residual=x)
+            m = layer.mlp
+            return ops.gelu_mlp(h, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, residual=x)
 
         for layer in vt.encoder.layers:
             x = self._maybe_remat(layer_fn, x, layer)

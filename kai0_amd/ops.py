@@ -775,6 +775,91 @@ class GegluMlpFn(torch.autograd.Function):
         return dx, _grad_ret(wg, dwg), _grad_ret(wu, dwu), _grad_ret(wd, dwd), (dout if ctx.has_res else None)
 
 
+_PAD_MLP_ROWS = os.environ.get("KAI0_PAD_MLP_ROWS", "1") != "0"  # diagnostics: 0 = unpadded [M, F] intermediates
+
+
+class GeluMlpFn(torch.autograd.Function):
+    """SigLIP's MLP `fc2(gelu_tanh(fc1(x))) + residual` (modeling_siglip.py:348-362 + the residual add of :476-478) as one
+    autograd node, so that the [M, F] intermediates (fc1 pre-activation, its GELU, and their gradients) can live in
+    buffers whose rows are padded to a multiple of 128 bytes: F = 4304 gives 8608-byte rows, and GEMM tiles that start
+    mid-line cost the K = 4304 / N = 4304 GEMMs 15-18 % (tools/gemm_align_probe.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        _chk(x, BF16, "gelu_mlp.x")
+        M, D = x.shape
+        F = w1.shape[0]
+        ldh = round_up(F, 64) if _PAD_MLP_ROWS else F
+        dev = x.device
+        pre = torch.empty((M, ldh), dtype=BF16, device=dev)
+        h = torch.empty((M, ldh), dtype=BF16, device=dev)
+        gemm(x, w1, h, M=M, N=F, K=D, lda=D, ldb=D, ldc=ldh, bias=b1, act=1, pre_out=pre, split_k=1)
+        out = torch.empty((M, w2.shape[0]), dtype=BF16, device=dev)
+        gemm(h, w2, out, M=M, N=w2.shape[0], K=F, lda=ldh, ldb=F, ldc=w2.shape[0], bias=b2, residual=residual,
+             ldr=w2.shape[0], split_k=pick_split_k(M, w2.shape[0], F))  # fmt: skip
+        ctx.save_for_backward(x, w1, w2, pre, h)
+        ctx.biases = (b1, b2)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, w2, pre, h = ctx.saved_tensors
+        b1, b2 = ctx.biases
+        dout = dout.contiguous()
+        M, D = x.shape
+        F, Do = w1.shape[0], w2.shape[0]
+        ldh = pre.shape[1]
+        dev = x.device
+        big = M >= 4096
+
+        def colsum(dy, N, ld, b):
+            db = _grad_dst(b, b.dtype)
+            scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=dev)
+            _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, ld, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
+                      int(b.dtype == F32), _stream())  # fmt: skip
+            return _grad_ret(b, db)
+
+        dw2 = db2 = dw1 = db1 = dx = None
+        if ctx.needs_input_grad[3]:
+            dw2 = _grad_dst(w2, BF16)
+            gemm(dout, h, dw2, M=Do, N=F, K=M, a_kc=False, b_kc=False, lda=Do, ldb=ldh, ldc=F, split_k=pick_split_k(Do, F, M))
+            dw2 = _grad_ret(w2, dw2)
+        if b2 is not None and ctx.needs_input_grad[4]:
+            db2 = colsum(dout, Do, Do, b2)
+        # dh = dout @ w2, then through the GELU: dpre = dh * gelu'(pre) (elementwise over the padded buffers; the padding
+        # columns hold don't-care values that no GEMM reads)
+        dh = torch.empty((M, ldh), dtype=BF16, device=dev)
+        if big:
+            w2t = transpose(w2)  # [F, Do]
+            gemm(dout, w2t, dh, M=M, N=F, K=Do, lda=Do, ldb=Do, ldc=ldh)
+            del w2t
+        else:
+            gemm(dout, w2, dh, M=M, N=F, K=Do, a_kc=True, b_kc=False, lda=Do, ldb=F, ldc=ldh)
+        dpre = torch.empty((M, ldh), dtype=BF16, device=dev)
+        _lib.call("kai0_gelu_bwd", dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), dh.numel(), _stream())
+        del dh
+        if ctx.needs_input_grad[1]:
+            dw1 = _grad_dst(w1, BF16)
+            gemm(dpre, x, dw1, M=F, N=D, K=M, a_kc=False, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k(F, D, M))
+            dw1 = _grad_ret(w1, dw1)
+        if b1 is not None and ctx.needs_input_grad[2]:
+            db1 = colsum(dpre, F, ldh, b1)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, D), dtype=BF16, device=dev)
+            if big:
+                w1t = transpose(w1)  # [D, F]
+                gemm(dpre, w1t, dx, M=M, N=D, K=F, lda=ldh, ldb=F, ldc=D)
+                del w1t
+            else:
+                gemm(dpre, w1, dx, M=M, N=D, K=F, a_kc=True, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k(M, D, F))
+        return dx, dw1, db1, dw2, db2, (dout if ctx.has_res else None)
+
+
+def gelu_mlp(x, w1, b1, w2, b2, residual=None):
+    return GeluMlpFn.apply(x, w1, b1, w2, b2, residual)
+
+
 def geglu_mlp(x, wg, wu, wd, residual=None):
     return GegluMlpFn.apply(x, wg, wu, wd, residual)
 
