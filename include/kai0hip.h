@@ -192,14 +192,15 @@ int kai0_rope_table(const int32_t* pos, const float* inv_freq, float* cos_out, f
                     kai0_stream_t stream);
 
 /* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C).
- * split_k > 1 slices the contraction over grid.z and combines with f32 atomics (summation order, hence the last
- * bits, then depend on scheduling) — used only for the long-contraction gradient reductions.
+ * split_k > 1 slices the contraction over grid.z into raw partial tiles workspace[split_k][M][N] (f32; size from
+ * kai0_gemm_f32_workspace_bytes) which a second launch sums in slice order — deterministic, no atomics.
  * Replaces the f32 islands: patch-embed conv as im2col GEMM (modeling_siglip.py:220-226), adaRMS
  * `dense` (modeling_gemma.py:83-104), time MLP and action in/out projections
  * (pi0_pytorch.py:100-105,264-297,364-371) and their backward. */
 int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                   float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int split_k,
-                  kai0_stream_t stream);
+                  void* workspace, int64_t workspace_bytes, kai0_stream_t stream);
+int64_t kai0_gemm_f32_workspace_bytes(int M, int N, int split_k);
 
 /* Few-row f32 Linear, out[m][n] = sum_k x[m][k] W[n][k] + bias[n] for 1 <= M <= 16 (weight-streaming GEMV batch):
  * the time-MLP and adaRMS `dense` modulations of all denoise steps (M = steps x batch). */

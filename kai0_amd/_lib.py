@@ -94,7 +94,7 @@ _PROTOS: dict[str, list] = {
                          c_i64, c_i64, c_f, c_p, c_i64, c_p],
     "kai0_transpose_strided_bf16": [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
     "kai0_rope_table": [c_p, c_p, c_p, c_p, c_i64, c_i, c_p],
-    "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
+    "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i64, c_p],
     "kai0_linear_rows_f32": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],
     "kai0_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p],
@@ -137,7 +137,8 @@ _PROTOS: dict[str, list] = {
     "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
 }  # fmt: skip
 
-EXPORTED_SYMBOLS = ("kai0_last_error", "kai0_skinny_workspace_bytes", "kai0_attn_decode_workspace_bytes", *_PROTOS.keys())
+EXPORTED_SYMBOLS = ("kai0_last_error", "kai0_skinny_workspace_bytes", "kai0_attn_decode_workspace_bytes", "kai0_gemm_f32_workspace_bytes",
+                    *_PROTOS.keys())
 
 _lib = None
 

@@ -17,7 +17,7 @@ constexpr int FBM = 64, FBN = 64, FBK = 16, PITCH = 80;
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
                                                        const float* __restrict__ B, int64_t sbk, int64_t sbn,
                                                        float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                       const float* __restrict__ bias, int accumulate, int k_chunk) {
+                                                       const float* __restrict__ bias, int accumulate, int k_chunk, float* __restrict__ ws) {
     __shared__ float As[FBK * PITCH];
     __shared__ float Bs[FBK * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // split-K: grid.z slices own k in [z*k_chunk, min(K, (z+1)*k_chunk)) and combine with f32 atomics
+    // split-K: grid.z slices own k in [z*k_chunk, min(K, (z+1)*k_chunk)) and write raw partial tiles ws[z][M][N]; the
+    // reduction kernel below sums them in slice order (deterministic) and applies bias / accumulate
     const int kbeg = blockIdx.z * k_chunk;
     const int kstop = min(K, kbeg + k_chunk);
     const bool split = gridDim.z > 1;
@@ -83,11 +84,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * 32 + i * 16 + 4 * g + r;
                 if (row >= M) continue;
+                if (split) {
+                    ws[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] + bv;
                 float* cp = C + (int64_t)row * ldc + col;
-                if (split) {
-                    atomicAdd(cp, v);
-                } else {
+                {
                     if (accumulate) v += *cp;
                     *cp = v;
                 }
@@ -95,11 +98,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
 }
 
+__global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C,
+                                                              int64_t ldc, int M, int N, const float* __restrict__ bias,
+                                                              int accumulate) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += ws[(int64_t)z * total + i];
+        if (bias) v += bias[col];
+        float* cp = C + (int64_t)row * ldc + col;
+        if (accumulate) v += *cp;
+        *cp = v;
+    }
+}
+
 }  // namespace
+
+KAI0_API int64_t kai0_gemm_f32_workspace_bytes(int M, int N, int split_k) {
+    return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
+}
 
 KAI0_API int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                            float* C, int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int split_k,
-                           kai0_stream_t stream) {
+                           void* workspace, int64_t workspace_bytes, kai0_stream_t stream) {
     KAI0_REQUIRE(A && B && C, "kai0_gemm_f32: null operand");
     KAI0_REQUIRE(M > 0 && N > 0 && K > 0, "kai0_gemm_f32: empty problem M=%d N=%d K=%d", M, N, K);
     if (split_k < 1) split_k = 1;
@@ -107,12 +129,18 @@ KAI0_API int kai0_gemm_f32(const float* A, int64_t sam, int64_t sak, const float
     split_k = (K + k_chunk - 1) / k_chunk;
     dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM, split_k), block(256, 1, 1);
     KAI0_REQUIRE(grid.y <= 65535, "kai0_gemm_f32: M=%d too large for grid.y", M);
-    if (split_k > 1 && !accumulate) {
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, (hipStream_t)stream);
-        KAI0_REQUIRE(e == hipSuccess, "kai0_gemm_f32: clearing C failed: %s", hipGetErrorString(e));
-    }
+    KAI0_REQUIRE(split_k == 1 || (workspace != nullptr && workspace_bytes >= (int64_t)split_k * M * N * 4),
+                 "kai0_gemm_f32: split_k=%d needs a workspace of split_k*M*N*4 bytes", split_k);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M,
-                       N, K, bias, accumulate, k_chunk);
+                       N, K, bias, accumulate, k_chunk, (float*)workspace);
+    if (split_k > 1) {
+        int rc = kai0_check_launch("kai0_gemm_f32");
+        if (rc) return rc;
+        int rb = (int)(((int64_t)M * N + 255) / 256);
+        if (rb > 1024) rb = 1024;
+        hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3(rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, split_k,
+                           C, ldc, M, N, bias, accumulate);
+    }
     return kai0_check_launch("kai0_gemm_f32");
 }
 

@@ -261,8 +261,9 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, out, M, N, K, bias=None, accumulate=Fals
     if split_k is None:  # long contraction, few 64x64 output tiles: spread K over the chip
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
         split_k = 1 if (tiles >= 512 or K < 512) else max(1, min(64, 1024 // tiles, K // 128))
+    ws = _workspace(split_k * M * N * 4, A.device) if split_k > 1 else None
     _lib.call("kai0_gemm_f32", A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, out.data_ptr(), out.stride(0), M, N, K,
-              _p(bias), int(accumulate), split_k, _stream())  # fmt: skip
+              _p(bias), int(accumulate), split_k, _p(ws), ws.numel() if ws is not None else 0, _stream())  # fmt: skip
     return out
 
 
