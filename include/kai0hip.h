@@ -361,8 +361,9 @@ int kai0_euler_step(float* x, const float* v, float dt, int64_t n, kai0_stream_t
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer (train_pytorch.py:469-475,557-561; optimizer.py:15-85).
- * sumsq: out[0] += sum(g^2) over a bf16 or f32 buffer (f32 atomics; caller zeroes out). */
-int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, kai0_stream_t stream);
+ * sumsq: out[0] += sum(g^2) over a bf16 or f32 buffer (caller zeroes out).  scratch: 4096 floats for the per-block partials,
+ * which a second launch adds in a fixed order (reproducible gradient norm; no atomics). */
+int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, float* scratch, kai0_stream_t stream);
 /* Fused AdamW on a flat shard: master/m/v f32, grad bf16 or f32, writes the bf16 (or f32) model copy.
  * clip_coef is read from device memory (coef[0]) so the step stays graph/stream ordered:
  *   g = grad * coef[0]; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

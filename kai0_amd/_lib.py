@@ -132,7 +132,7 @@ _PROTOS: dict[str, list] = {
     "kai0_mse_fwd": [c_p, c_p, c_p, c_i64, c_p],
     "kai0_mse_bwd": [c_p, c_p, c_p, c_p, c_i64, c_p],
     "kai0_euler_step": [c_p, c_p, c_f, c_i64, c_p],
-    "kai0_sumsq": [c_p, c_i, c_i64, c_p, c_p],
+    "kai0_sumsq": [c_p, c_i, c_i64, c_p, c_p, c_p],
     "kai0_clip_coef": [c_p, c_f, c_p, c_p, c_p],
     "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
 }  # fmt: skip

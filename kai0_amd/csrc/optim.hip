@@ -36,7 +36,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ g, 
             }
     }
     acc = block_sum<4>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;  // per-block partial; sumsq_finish_kernel adds them in a fixed order
+}
+
+// out[0] += sum of `n` block partials (n <= 4096), always in the same order: the global gradient norm, and with it the whole
+// training trajectory, is reproducible bit for bit (f32 atomics across blocks were not)
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) out[0] += acc;
 }
 
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef,
@@ -82,12 +92,14 @@ inline int opt_grid(int64_t n) {
 
 }  // namespace
 
-KAI0_API int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, kai0_stream_t stream) {
+KAI0_API int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, float* scratch, kai0_stream_t stream) {
     if (n <= 0) return 0;
+    KAI0_REQUIRE(scratch != nullptr, "kai0_sumsq: needs a scratch buffer of 4096 floats");
     KAI0_REQUIRE(((uintptr_t)g % 16) == 0, "kai0_sumsq: unaligned buffer");
     const int grid = opt_grid(g_f32 ? n / 4 + 1 : n / 8 + 1);
-    if (g_f32) hipLaunchKernelGGL((sumsq_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
-    else hipLaunchKernelGGL((sumsq_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    if (g_f32) hipLaunchKernelGGL((sumsq_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+    else hipLaunchKernelGGL((sumsq_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, grid, out);
     return kai0_check_launch("kai0_sumsq");
 }
 

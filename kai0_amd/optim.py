@@ -38,8 +38,16 @@ def adamw_step_(master, m, v, grad, param, *, lr, beta1, beta2, eps, wd, step: i
               None if clip_coef is None else clip_coef.data_ptr(), _stream())  # fmt: skip
 
 
+_SUMSQ_SCRATCH: dict = {}
+
+
 def sumsq_accumulate_(grad, out):
-    _lib.call("kai0_sumsq", grad.data_ptr(), int(grad.dtype == F32), grad.numel(), out.data_ptr(), _stream())
+    """out[0] += sum(grad^2), deterministic (block partials + ordered finish)."""
+    key = (grad.device.index, _stream())
+    scratch = _SUMSQ_SCRATCH.get(key)
+    if scratch is None:
+        scratch = _SUMSQ_SCRATCH[key] = torch.empty(4096, dtype=F32, device=grad.device)
+    _lib.call("kai0_sumsq", grad.data_ptr(), int(grad.dtype == F32), grad.numel(), out.data_ptr(), scratch.data_ptr(), _stream())
 
 
 def clip_coef_(sumsq, max_norm: float, coef, norm_out):

@@ -142,6 +142,11 @@ def test_backward_at_full_size_against_closed_form_and_one_step_lowers_the_loss(
                                                                "encoder.layers.0.mlp.fc1.weight", "embed_tokens.weight"))]  # fmt: skip
     # (layer 17 of the PREFIX tower gets no gradient at all: its output feeds nothing the loss sees — as in the reference)
     assert len(some) >= 5 and all(p.grad is not None and torch.isfinite(p.grad.float()).all() and float(p.grad.float().abs().sum()) > 0 for p in some)
+    # the backward is reproducible bit for bit (ordered split-K / norm / column-sum reductions, no atomics)
+    first = [p.grad.clone() for p in some] + [m.action_out_proj.weight.grad.clone()]
+    m.zero_grad(set_to_none=True)
+    m(obs, a, noise=n, time=t).mean().backward()
+    assert all(torch.equal(g0, p.grad) for g0, p in zip(first, [*some, m.action_out_proj.weight]))
     m.zero_grad(set_to_none=True)
     # Adam's first steps move every weight by ~lr whatever the gradient scale: with 2048-16384-wide contractions a layer's
     # output changes by ~lr * width, so the step must be small (the reference warms up from 2.5e-8 to 2.5e-5)
