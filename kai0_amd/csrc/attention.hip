@@ -36,6 +36,8 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
 struct AttnArgs {
     const bf16_t* Q;
     const bf16_t* K;
@@ -53,8 +55,11 @@ struct AttnArgs {
 };
 
 // NKS = number of 64-wide K sub-tiles (HD <= 64*NKS); VC = V tile columns (128 or 256); OMT = VC/16 output d-tiles
-template <int NKS, int VC>
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
+// QT = 16-row query tiles per wave.  2: four waves per 128-row block (one per SIMD); 1: eight waves (two per SIMD), so that one
+// wave's MFMAs overlap the other's softmax VALU work and LDS reads — the block, its K / V tiles and LDS footprint are the same.
+template <int NKS, int VC, int QT>
+__global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int WAVES = 128 / (16 * QT);
     constexpr int OMT = VC / 16;
     constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
     constexpr int K_BYTES = NKS * 8192;             // NKS x [64 keys][64 d] bf16
@@ -63,10 +68,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int STAGE = K_BYTES + V_BYTES;
     constexpr int V_LPR = V_ROWB / 16;              // lanes per V row (16 or 32)
     constexpr int V_RPP = 64 / V_LPR;               // key rows per DMA piece (4 or 2)
-    constexpr int NKP = NKS * 8 / 4;                // K DMA pieces per wave per tile
-    constexpr int NVP = (64 / V_RPP) / 4;           // V DMA pieces per wave per tile
+    constexpr int NKP = NKS * 8 / WAVES;            // K DMA pieces per wave per tile
+    constexpr int NVP = (64 / V_RPP) / WAVES;       // V DMA pieces per wave per tile
+    static_assert(NKP >= 1 && NVP >= 1, "too many waves for this tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* pbuf_all = smem + 2 * STAGE;              // 4 waves x [32 rows][64 keys] bf16 (P transposition scratch)
+    char* pbuf_all = smem + 2 * STAGE;              // WAVES x [16 QT rows][64 keys] bf16 (P transposition scratch)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,14 +86,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
     bf16_t* Pb = p.P + (int64_t)z * p.sP;
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)OOB, 0x00020000);
-    const int row0 = blockIdx.x * 128 + wave * 32;   // first query row of this wave
+    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Pb, 0, (int)OOB, 0x00020000);
+    const int row0 = blockIdx.x * 128 + wave * (16 * QT);   // first query row of this wave
     const int ntiles = (p.Sk + 63) / 64;
     const uint32_t ldk2 = (uint32_t)p.ldk * 2, ldv2 = (uint32_t)p.ldv * 2;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[row][32*ks + 8g .. +8] ----------------
-    bf16x8 qf[2][KSTEPS];
+    bf16x8 qf[QT][KSTEPS];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < QT; ++nt) {
         const int r = row0 + nt * 16 + l15;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -100,9 +107,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
         }
     }
     // per-lane query codes (mask): the query position of folded row r is q0 + r / H
-    int qc[2];
+    int qc[QT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < QT; ++nt) {
         const int r = row0 + nt * 16 + l15;
         qc[nt] = INT_MAX;
         if (p.qcode != nullptr) qc[nt] = r < p.rows ? p.qcode[z1 * p.qcode_ld + p.q0 + r / p.H] : -1;
@@ -139,11 +146,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
     };
 
     // S^T tile of this wave: [64 keys][32 queries] = 4 x 2 MFMA tiles; A = K rows (LDS), B = Q (registers)
-    auto logits = [&](const char* tk, f32x4 (&s)[4][2]) {
+    auto logits = [&](const char* tk, f32x4 (&s)[4][QT]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < QT; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const char* sub = tk + (ks >> 1) * 8192;
@@ -153,45 +160,55 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
                 const int row = mt * 16 + l15;
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sub + row * 128 + ((chunk ^ (row & 7)) << 4));
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < QT; ++nt)
                     s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[nt][ks], s[mt][nt], 0, 0, 0);
             }
         }
     };
     // logits with the reference's rounding, masked: element (mt, nt, r) is key kt*64 + mt*16 + 4g + r, query column l15
-    auto finish_logits = [&](int kt, f32x4 (&s)[4][2]) {
+    // key codes of tile kt for this lane's 16 keys (mt*16 + 4g + r): loaded BEFORE the tile's MFMAs so that the global
+    // latency hides behind them (inside finish_logits they cost one exposed load latency per tile and pass)
+    auto load_kcodes = [&](int kt, int (&kc)[4][4]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int key = kt * 64 + mt * 16 + 4 * g;
-            int kc[4] = {0, 0, 0, 0};
-            if (p.kcode != nullptr) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kc[r] = (key + r < p.Sk) ? p.kcode[z1 * p.kcode_ld + key + r] : INT_MAX;
-            }
+            for (int r = 0; r < 4; ++r)
+                kc[mt][r] = p.kcode == nullptr ? 0 : ((key + r < p.Sk) ? p.kcode[z1 * p.kcode_ld + key + r] : INT_MAX);
+        }
+    };
+    auto finish_logits = [&](int kt, f32x4 (&s)[4][QT], const int (&kc)[4][4]) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+        for (int mt = 0; mt < 4; ++mt) {
+            const int key = kt * 64 + mt * 16 + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = rbf(rbf(s[mt][nt][r]) * p.scale);
-                    const bool ok = (key + r < p.Sk) && (kc[r] <= qc[nt]);
+                    const bool ok = (key + r < p.Sk) && (kc[mt][r] <= qc[nt]);
                     s[mt][nt][r] = ok ? v : -INFINITY;
                 }
         }
     };
 
     // ================================ pass 1: row max and row sum =====================================================
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int nt = 0; nt < QT; ++nt) { m_run[nt] = -INFINITY; l_run[nt] = 0.f; }
     stage(0, 0, false);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, false);
-        f32x4 s[4][2];
+        int kc[4][4];
+        load_kcodes(kt, kc);
+        f32x4 s[4][QT];
         logits(smem + buf * STAGE, s);
-        finish_logits(kt, s);
+        finish_logits(kt, s, kc);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < QT; ++nt) {
             float tmax = -INFINITY;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -212,9 +229,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
         lds_barrier();
     }
     // combine the 4 lane groups (each saw the keys 4g..4g+3 of every 16-key block) of a query column
-    float inv_l[2];
+    float inv_l[QT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < QT; ++nt) {
         float m = m_run[nt], l = l_run[nt];
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -228,12 +245,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
     }
 
     // ================================ pass 2: P and O = P V ===========================================================
-    f32x4 o[OMT][2];
+    f32x4 o[OMT][QT];
 #pragma unroll
     for (int mt = 0; mt < OMT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    char* pbuf = pbuf_all + wave * 4096;
+        for (int nt = 0; nt < QT; ++nt) o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char* pbuf = pbuf_all + wave * (QT * 2048);
     stage(0, 0, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -242,15 +259,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
         if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, true);
         const char* tk = smem + buf * STAGE;
         const char* tv = tk + K_BYTES;
-        f32x4 s[4][2];
+        int kc[4][4];
+        load_kcodes(kt, kc);
+        f32x4 s[4][QT];
         logits(tk, s);
-        finish_logits(kt, s);
+        finish_logits(kt, s, kc);
         // final probabilities, rounded to bf16 exactly once (what the reference multiplies V with)
-        bf16x4 pb[4][2];
+        bf16x4 pb[4][QT];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < QT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = (m_run[nt] > -INFINITY) ? __expf(s[mt][nt][r] - m_run[nt]) * inv_l[nt] : 0.f;
@@ -261,16 +280,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < QT; ++nt)
                     *reinterpret_cast<bf16x4*>(pbuf + (nt * 16 + l15) * 128 + (mt * 16 + 4 * g) * 2) = pb[mt][nt];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            // buffer stores with an out-of-range offset for the lanes that have nothing to write: the instruction is ALWAYS
+            // issued, so the wait at the end of the tile can count these 2 QT stores as the youngest memory operations and
+            // need not sit out their acknowledgement (vmcnt counts stores too; a plain vmcnt(0) there cost ~1 us per tile)
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < 2 * QT; ++it) {
                 const int lr = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
                 const int r = row0 + lr, key = kt * 64 + c8;
-                if (r < p.rows && key < p.ldp)
-                    *reinterpret_cast<bf16x8*>(Pb + (int64_t)r * p.ldp + key) = *reinterpret_cast<const bf16x8*>(pbuf + lr * 128 + c8 * 2);
+                const u32x4 pv = *reinterpret_cast<const u32x4*>(pbuf + lr * 128 + c8 * 2);
+                const uint32_t off = (r < p.rows && key < p.ldp) ? (uint32_t)(((int64_t)r * p.ldp + key) * 2) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(pv, p_rsrc, (int)off, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -279,9 +302,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
         // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 pf[2];
+            bf16x8 pf[QT];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int nt = 0; nt < QT; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
             const int r_lo = kk * 32 + 4 * g + (l15 >> 2);   // key row this lane addresses for the transpose read
             const int r_hi = r_lo + 16;
 #pragma unroll
@@ -294,17 +317,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs p) {
                     (LDS_PTR(bf16x4))(tv + r_hi * V_ROWB + ((chunk ^ ((r_hi & 7) << 1)) << 4) + sub));
                 const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < QT; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the DMA of tile kt+1 (issued at the top of this iteration) must have landed; the P stores issued after it may fly
+        if (p.P != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
     }
     // zero the padding columns [64*ntiles, ldp) of P (none when ldp <= 64*ntiles) — the tiles above already wrote
     // zeros for keys in [Sk, 64*ntiles)
     // ---- O: lane (q = l15, g) holds O^T rows d = 16 mt + 4g + r ----------------------------------------------------
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < QT; ++nt) {
         const int r = row0 + nt * 16 + l15;
         if (r >= p.rows) continue;
 #pragma unroll
@@ -333,6 +358,7 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d->H >= 1, "kai0_attn_fwd: H must be >= 1");
     KAI0_REQUIRE((int64_t)d->Sk * d->ldk * 2 < (int64_t)0x7FFF0000 && (int64_t)d->Sk * d->ldv * 2 < (int64_t)0x7FFF0000,
                  "kai0_attn_fwd: K/V span more than 2 GiB per batch entry");
+    KAI0_REQUIRE(d->P == nullptr || (int64_t)d->rows * d->ldp * 2 < (int64_t)0x7FFF0000, "kai0_attn_fwd: P spans more than 2 GiB per batch entry");
     if (d->rows <= 0 || d->Sk <= 0) return 0;
     AttnArgs p;
     p.Q = (const bf16_t*)d->Q; p.K = (const bf16_t*)d->K; p.V = (const bf16_t*)d->V;
@@ -346,22 +372,29 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     p.qcode_ld = d->qcode_ld; p.kcode_ld = d->kcode_ld;
     p.scale = d->scale;
     const int batch = d->batch > 0 ? d->batch : 1;
-    dim3 grid((d->rows + 127) / 128, batch, 1), block(256, 1, 1);
+    dim3 grid((d->rows + 127) / 128, batch, 1);
     hipStream_t s = (hipStream_t)stream;
-#define KAI0_ATTN_LAUNCH(NKS, VC)                                                                                  \
+#define KAI0_ATTN_LAUNCH(NKS, VC, QT)                                                                              \
     do {                                                                                                          \
         constexpr int LDS = 2 * (NKS * 8192 + 64 * VC * 2) + 4 * 4096;                                            \
         static bool attr_set = false;                                                                             \
-        auto kern = attn_fwd_kernel<NKS, VC>;                                                                     \
+        auto kern = attn_fwd_kernel<NKS, VC, QT>;                                                                 \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             KAI0_REQUIRE(e == hipSuccess, "kai0_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL(kern, grid, block, LDS, s, p);                                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(128 / (16 * QT) * 64), LDS, s, p);                                    \
     } while (0)
-    if (d->HD <= 128) KAI0_ATTN_LAUNCH(2, 128);
-    else KAI0_ATTN_LAUNCH(4, 256);
+    // KAI0_ATTN_QT=2: the former four-wave blocks (diagnostics)
+    static const int qt = [] { const char* e = getenv("KAI0_ATTN_QT"); return e ? atoi(e) : 1; }();
+    if (d->HD <= 128) {
+        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2);
+        else KAI0_ATTN_LAUNCH(2, 128, 1);
+    } else {
+        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2);
+        else KAI0_ATTN_LAUNCH(4, 256, 1);
+    }
 #undef KAI0_ATTN_LAUNCH
     return kai0_check_launch("kai0_attn_fwd");
 }
