@@ -26,3 +26,13 @@ if e:
     a, b = e[0], e[1]
     for r0, r1 in zip(seg[a + 1:b + 1][:60], seg[a + 2:b + 2][:60]):
         print(f"   {r0[0].replace('(anonymous namespace)::', '')[:50]:52s} dur {(r0[2] - r0[1]) / 1e3:6.1f} us  gap {(r1[1] - r0[2]) / 1e3:6.1f}")
+
+
+def dump(title, a, n):
+    print(title)
+    for r in seg[a : a + n]:
+        print(f"   {r[0].replace('(anonymous namespace)::', '').replace('void ', '')[:64]:66s} dur {(r[2] - r[1]) / 1e3:6.1f} us")
+
+
+dump("SigLIP tower, first kernels:", 0, 26)
+dump("prefix pass, first kernels after the tower:", i0, 30)
