@@ -63,6 +63,7 @@ int kai0_device_info(int device, int* n_cu, int* lds_bytes, char* arch_name64);
  *                  v = bf16(bf16(gelu_tanh(g)) * u) with g = aux1[row][col]
  *   if act == 3:   GeGLU backward in the down-projection dgrad: v = dh; pre_out = du = bf16(dh * bf16(gelu_tanh(g)));
  *                  v = dg = bf16(bf16(dh * u) * gelu_tanh'(g)) with g = aux1, u = aux2
+ *   if act == 5:   GELU backward in the dgrad that produces dh (SigLIP fc2 -> fc1): v = bf16(dh * gelu_tanh'(pre)), pre = aux1
  *   if gate:       v = bf16(v * gate[row / gate_rpb][col])          (_gated_residual, modeling_gemma.py:209-227)
  *   if residual:   v = bf16(v + residual[row][col])
  *   if accumulate: v = v + C_old  (f32 out: exact; bf16 out: rounded once)

@@ -167,6 +167,16 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
             v[e + 1] = R(R(v[e + 1] * bf2f(uv[e + 1])) * gr[1]);
         }
         *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = du;
+    } else if (p.act == 5) {
+        // GELU backward fused into the dgrad that produces dh (SigLIP fc2): C <- bf16(dh * gelu_tanh'(pre)), pre = aux1
+        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(p.aux1 + cz + orow * p.ldc + ccol);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            f32x2 gl, gr;
+            gelu_tanh_both2(f32x2{bf2f(pv[e]), bf2f(pv[e + 1])}, gl, gr);
+            v[e] = R(v[e] * gr[0]);
+            v[e + 1] = R(v[e + 1] * gr[1]);
+        }
     }
     if (p.gate != nullptr) {
         bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.gate + (int64_t)(row / p.gate_rpb) * p.gate_ld + ccol);
@@ -636,6 +646,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                         ov[e + 1] = f2bf(b[1]);
                     }
                     *reinterpret_cast<bf16x8*>(p.pre_out + o) = du;
+                } else if (p.act == 5) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2 gl, gr;
+                        gelu_tanh_both2(f32x2{bf2f(s0[it][e]), bf2f(s0[it][e + 1])}, gl, gr);
+                        const f32x2 b = rbf2(f32x2{v[e], v[e + 1]}) * gr;
+                        ov[e] = f2bf(b[0]);
+                        ov[e + 1] = f2bf(b[1]);
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ov[e] = f2bf((bf2f(s0[it][e]) * (v[e] - ds[it])) * p.scale);
@@ -758,10 +777,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
-    KAI0_REQUIRE(d->act >= 0 && d->act <= 4, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act >= 0 && d->act <= 5, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act != 5 || (d->aux1 && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
+                 "kai0_gemm_bf16: act=5 (fused GELU backward) needs aux1 = pre-activation, plain bf16 output");
     KAI0_REQUIRE(d->act != 4 || (d->aux1 && d->rowvec && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
                  "kai0_gemm_bf16: act=4 (fused softmax backward) needs aux1 = P, rowvec = D, plain bf16 output");
-    KAI0_REQUIRE(d->act < 2 || d->act == 4 || ((d->pre_out || d->act == 2) && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
+    KAI0_REQUIRE(d->act < 2 || d->act >= 4 || ((d->pre_out || d->act == 2) && d->aux1 && (d->act == 2 || d->aux2) && !d->out_f32 && (d->N % 8) == 0),
                  "kai0_gemm_bf16: act=%d (fused GeGLU) needs pre_out and aux inputs, bf16 output", d->act);
     KAI0_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "kai0_gemm_bf16: nseg=%d", d->nseg);
     if (d->nseg > 0) {

@@ -828,18 +828,14 @@ class GeluMlpFn(torch.autograd.Function):
             dw2 = _grad_ret(w2, dw2)
         if b2 is not None and ctx.needs_input_grad[4]:
             db2 = colsum(dout, Do, Do, b2)
-        # dh = dout @ w2, then through the GELU: dpre = dh * gelu'(pre) (elementwise over the padded buffers; the padding
-        # columns hold don't-care values that no GEMM reads)
-        dh = torch.empty((M, ldh), dtype=BF16, device=dev)
+        # dpre = (dout @ w2) * gelu'(pre): the GELU backward runs in the dgrad GEMM's epilogue (kai0hip.h act 5)
+        dpre = torch.empty((M, ldh), dtype=BF16, device=dev)
         if big:
             w2t = transpose(w2)  # [F, Do]
-            gemm(dout, w2t, dh, M=M, N=F, K=Do, lda=Do, ldb=Do, ldc=ldh)
+            gemm(dout, w2t, dpre, M=M, N=F, K=Do, lda=Do, ldb=Do, ldc=ldh, act=5, aux1=pre)  # dh never reaches HBM
             del w2t
         else:
-            gemm(dout, w2, dh, M=M, N=F, K=Do, a_kc=True, b_kc=False, lda=Do, ldb=F, ldc=ldh)
-        dpre = torch.empty((M, ldh), dtype=BF16, device=dev)
-        _lib.call("kai0_gelu_bwd", dh.data_ptr(), pre.data_ptr(), dpre.data_ptr(), dh.numel(), _stream())
-        del dh
+            gemm(dout, w2, dpre, M=M, N=F, K=Do, a_kc=True, b_kc=False, lda=Do, ldb=F, ldc=ldh, act=5, aux1=pre)
         if ctx.needs_input_grad[1]:
             dw1 = _grad_dst(w1, BF16)
             gemm(dpre, x, dw1, M=F, N=D, K=M, a_kc=False, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k(F, D, M))

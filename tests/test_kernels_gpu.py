@@ -396,6 +396,29 @@ def test_geglu_mlp_fused(ops, M, D, Fd):
     assert torch.equal(res.grad, dy)
 
 
+@pytest.mark.parametrize("M,D,Fd", [(200, 64, 136), (4352, 256, 520), (4100, 1152, 4304)])
+def test_gelu_mlp_fused(ops, M, D, Fd):
+    """SigLIP MLP as one node: padded [M, F] intermediates, GELU backward in the dgrad epilogue (act 5), bias gradients over
+    the padded rows; both the small-M (NN dgrad) and the many-rows (transposed-weight NT dgrad, fast epilogue) paths."""
+    x = rnd(M, D, seed=1).requires_grad_(True)
+    w1 = rnd(Fd, D, seed=2, scale=0.05).requires_grad_(True)
+    b1 = rnd(Fd, seed=3, scale=0.1).requires_grad_(True)
+    w2 = rnd(D, Fd, seed=4, scale=0.05).requires_grad_(True)
+    b2 = rnd(D, seed=5, scale=0.1).requires_grad_(True)
+    res = rnd(M, D, seed=6).requires_grad_(True)
+    dy = rnd(M, D, seed=7)
+    out = ops.gelu_mlp(x, w1, b1, w2, b2, res)
+    out.backward(dy)
+    ref_in = [t.detach().float().requires_grad_(True) for t in (x, w1, b1, w2, b2, res)]
+    xr, w1r, b1r, w2r, b2r, rr = ref_in
+    ref = torch.nn.functional.gelu(xr @ w1r.t() + b1r, approximate="tanh") @ w2r.t() + b2r + rr
+    ref.backward(dy.float())
+    assert rel_err(out, ref) < 6e-3
+    for n, t, r in zip(("dx", "dw1", "db1", "dw2", "db2"), (x, w1, b1, w2, b2), ref_in):
+        assert rel_err(t.grad, r.grad) < 1.5e-2, f"{n}: {rel_err(t.grad, r.grad):.3e}"
+    assert torch.equal(res.grad, dy)
+
+
 def _rope_ref(x, pos, inv_freq, inverse=False):
     """modeling_gemma.py:149-194 in bf16: x [B, S, H, HD], pos [B, S]."""
     freqs = pos[:, :, None].float() * inv_freq[None, None, :]
