@@ -980,6 +980,8 @@ class EmbedFn(torch.autograd.Function):
 
 
 def embed(table, tokens, scale):
+    if tokens.dtype in (torch.int32, torch.int16, torch.uint8):  # nn.Embedding takes int32 indices too (the data pipeline's dtype)
+        tokens = tokens.to(torch.int64)
     return EmbedFn.apply(table, tokens.contiguous(), scale)
 
 

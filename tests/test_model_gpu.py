@@ -290,3 +290,35 @@ def test_advantage_estimator_against_reference_executed():
               "paligemma_with_expert.paligemma.model.language_model.layers.1.self_attn.q_proj.weight"):
         rg = rel(pm[k].grad, po[k].grad)
         assert rg <= 5e-2, (k, rg)
+
+
+def test_data_loader_device_feed_drives_the_trainer():
+    """FakeDataset -> transforms -> TorchDataLoader -> DeviceFeeder (pinned memory, side-stream H2D, event hand-off) ->
+    Trainer.train_step on the GPU: batches arrive on the device in loader order and the step consumes them."""
+    from tiny import tiny_cfgs
+
+    from kai0_amd import data_loader as dl
+    from kai0_amd.model import PI0Pytorch
+    from kai0_amd.train import Trainer
+
+    dev = torch.device("cuda:0")
+    pcfg, _ = tiny_cfgs()
+    torch.manual_seed(0)
+    m = PI0Pytorch(pcfg).to(dev)
+    m.train_augmentation = False
+    m.train()
+    ds = dl.FakeDataset(pcfg, 12)
+    # the fake tokens are U{0..2047} as in the reference; the tiny test vocabulary has 304 entries
+    loader = dl.create_torch_data_loader(ds, 4, num_batches=3, transforms=[lambda d: {**d, "tokenized_prompt": d["tokenized_prompt"] % 300}])
+    tr = Trainer(m, peak_lr=1e-4, warmup_steps=1, decay_steps=10, end_lr=1e-4)
+    seen = []
+    for obs, actions in dl.DeviceFeeder(loader, dev, depth=2):
+        assert obs.images["base_0_rgb"].device == dev and obs.images["base_0_rgb"].shape == (4, 3, 56, 56) and actions.device == dev
+        seen.append(actions.cpu())
+        loss = tr.train_step(obs, actions)
+        assert torch.isfinite(loss)
+    import numpy as np
+
+    assert len(seen) == 3
+    for i, a in enumerate(seen):
+        assert torch.equal(a, torch.as_tensor(np.stack([ds[4 * i + j]["actions"] for j in range(4)])))
