@@ -242,6 +242,22 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
     return max(1, min(16, 768 // tiles, K // 256))
 
 
+# Split-K of the weight-gradient GEMMs (TN, contraction = B*S rows) whose output has few 256x256 tiles, measured on MI355X
+# with tools/tn_split_probe.py (us per launch at split 1/2/3/4/6/8): the best split fills ONE round of the 256 CUs
+# (tiles x split <= 256), and fewer, longer chunks win when that leaves CUs idle anyway — a CU that shares the chip with
+# fewer running blocks stages its tiles faster.  Exact pi0.5 shapes at B = 32 first, then the rule they follow.
+_WGRAD_SPLIT = {(1152, 4304, 24576): 3, (4304, 1152, 24576): 3, (3456, 1152, 24576): 2, (1152, 1152, 24576): 6,
+                (2560, 2048, 30976): 3, (2048, 2048, 30976): 4}  # fmt: skip
+_WGRAD_SPLIT_TUNED = os.environ.get("KAI0_WGRAD_SPLIT", "tuned") != "old"
+
+
+def pick_split_k_wgrad(M: int, N: int, K: int) -> int:
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    if not _WGRAD_SPLIT_TUNED or t256 >= 200 or K < 4096:
+        return pick_split_k(M, N, K)
+    return _WGRAD_SPLIT.get((M, N, K)) or max(1, min(6, 256 // t256, K // 2048))
+
+
 def linear_fwd(x, w, bias=None, residual=None, act=0, want_pre=False, gate=None, gate_rpb=0, out=None):
     """y = epilogue(x @ w.T) for flat bf16 x [M,K], w [N,K]."""
     M, K = x.shape
@@ -335,7 +351,7 @@ class LinearFn(torch.autograd.Function):
             # directly, so no gradient copy is needed afterwards (sharded.py)
             dw = _grad_dst(w, BF16)
             # dw[N,K] = dy[M,N]^T @ x[M,K]  (both stored [contraction][cols])
-            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k(N, K, M))
+            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _grad_dst(ctx.bias, ctx.bias_dtype)
             scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=x.device)
@@ -448,7 +464,7 @@ class LinearMultiFn(torch.autograd.Function):
             tmp = dwcat is None
             if tmp:
                 dwcat = torch.empty((Nt, K), dtype=BF16, device=dev)
-            gemm(dy, x, dwcat, M=Nt, N=K, K=M, a_kc=False, b_kc=False, lda=Nt, ldb=K, ldc=K, split_k=pick_split_k(Nt, K, M))
+            gemm(dy, x, dwcat, M=Nt, N=K, K=M, a_kc=False, b_kc=False, lda=Nt, ldb=K, ldc=K, split_k=pick_split_k_wgrad(Nt, K, M))
             r = 0
             for i, (w, dst) in enumerate(zip(ws, dsts)):
                 if tmp:
@@ -492,7 +508,7 @@ class LinearMultiFn(torch.autograd.Function):
                 first = False
             if ctx.needs_input_grad[2 + i]:
                 dw = _grad_dst(w, BF16)
-                gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k(N, K, M))
+                gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M))
                 dws[i] = _grad_ret(w, dw)
             if b is not None and ctx.needs_input_grad[2 + n + i]:
                 db = _grad_dst(b, b.dtype)
@@ -753,7 +769,7 @@ class GegluMlpFn(torch.autograd.Function):
 
         def wgrad(dy, inp, w, n, k):
             dw = _grad_dst(w, BF16)
-            gemm(dy, inp, dw, M=n, N=k, K=M, a_kc=False, b_kc=False, lda=n, ldb=k, ldc=k, split_k=pick_split_k(n, k, M))
+            gemm(dy, inp, dw, M=n, N=k, K=M, a_kc=False, b_kc=False, lda=n, ldb=k, ldc=k, split_k=pick_split_k_wgrad(n, k, M))
             return dw
 
         dwd = wgrad(dout, h, wd, D, F) if ctx.needs_input_grad[3] else None
@@ -824,7 +840,7 @@ class GeluMlpFn(torch.autograd.Function):
         dw2 = db2 = dw1 = db1 = dx = None
         if ctx.needs_input_grad[3]:
             dw2 = _grad_dst(w2, BF16)
-            gemm(dout, h, dw2, M=Do, N=F, K=M, a_kc=False, b_kc=False, lda=Do, ldb=ldh, ldc=F, split_k=pick_split_k(Do, F, M))
+            gemm(dout, h, dw2, M=Do, N=F, K=M, a_kc=False, b_kc=False, lda=Do, ldb=ldh, ldc=F, split_k=pick_split_k_wgrad(Do, F, M))
             dw2 = _grad_ret(w2, dw2)
         if b2 is not None and ctx.needs_input_grad[4]:
             db2 = colsum(dout, Do, Do, b2)
@@ -838,7 +854,7 @@ class GeluMlpFn(torch.autograd.Function):
             gemm(dout, w2, dpre, M=M, N=F, K=Do, a_kc=True, b_kc=False, lda=Do, ldb=F, ldc=ldh, act=5, aux1=pre)
         if ctx.needs_input_grad[1]:
             dw1 = _grad_dst(w1, BF16)
-            gemm(dpre, x, dw1, M=F, N=D, K=M, a_kc=False, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k(F, D, M))
+            gemm(dpre, x, dw1, M=F, N=D, K=M, a_kc=False, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k_wgrad(F, D, M))
             dw1 = _grad_ret(w1, dw1)
         if b1 is not None and ctx.needs_input_grad[2]:
             db1 = colsum(dpre, F, ldh, b1)
