@@ -212,6 +212,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # NCCL_DEBUG=VERSION (set on the bench boxes) makes RCCL print a banner through C stdio, which a pipe flushes at
+        # process exit — i.e. AFTER the JSON line this script owes its caller as the last line of stdout.  Banner off;
+        # anything else a user asked for (WARN, INFO, TRACE) stays, and every rank flushes C stdio before rank 0 prints.
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
         dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
 
     cfg = Pi0Config()
@@ -256,6 +261,15 @@ def main():
     elapsed = float(el)
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+    if world > 1:  # every rank empties its C stdio buffers (RCCL warnings) now, so nothing of theirs can follow rank 0's line
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        dist.barrier()
 
     if rank == 0:
         out = {
@@ -318,6 +332,12 @@ def main():
             out["p50_action_chunk_ms"] = measure_latency(model, cfg, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        try:  # whatever native libraries still hold in C stdio buffers goes out first: the JSON line must be the last one
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
