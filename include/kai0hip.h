@@ -254,6 +254,12 @@ int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratc
  * out = bf16( bf16(x*cos) + bf16(rot(x)*sin) ).  inverse=1 applies the transpose (backward). */
 int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_freq, int B, int S, int64_t s_ld_rows,
                       int64_t row0, int H, int HD, int inverse, kai0_stream_t stream);
+/* The same rotation out of place and fully strided (elements): dst[b][s] = rope(src[b][s], pos[b * pos_bs + s]) for B x S
+ * rows of H heads.  Used to scatter a segment's q / k into the joint [B][S_total] attention buffers (and to gather the
+ * gradients back, inverse = 1) with the rotation applied on the way (gemma_pytorch.py:181-195). */
+int kai0_rope_copy(const void* src, void* dst, const int32_t* pos, const float* inv_freq, int B, int S, int H, int HD,
+                   int64_t src_bs, int64_t src_ld, int64_t dst_bs, int64_t dst_ld, int64_t pos_bs, int inverse,
+                   kai0_stream_t stream);
 
 /* Masked row softmax for the prefix-LM mask (pi0_pytorch.py:52-81,156-159; modeling_gemma.py:243-248).
  * scores bf16 [B][Sq*H][ld] already scaled; row r of batch b is query s = q0 + r / H.

@@ -106,6 +106,7 @@ _PROTOS: dict[str, list] = {
     "kai0_reduce_partials": [c_p, c_i, c_i, c_i64, c_p, c_i, c_p],
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
+    "kai0_rope_copy": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i, c_p],
     "kai0_softmax_mask_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
     "kai0_siglip_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_f, c_p],
     "kai0_rowdot_bf16": [c_p, c_p, c_p, c_i64, c_i, c_p],

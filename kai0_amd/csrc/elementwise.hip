@@ -30,11 +30,16 @@ inline int ew_grid(int64_t n_items, int per_block) {
 }
 
 // ---------------------------------------------------------------------------------------------- RoPE
-// x: [B][S_ld rows][H][HD]; thread owns 4 consecutive frequency indices i4..i4+3 of one (b,s) row and walks
-// the heads, so the sin/cos of a position is computed once and shared by all heads.
-__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const int32_t* __restrict__ pos,
-                                                   const float* __restrict__ inv_freq, int B, int S, int64_t s_ld,
-                                                   int64_t row0, int H, int HD, int inverse) {
+// dst[b][s][h][:] = rope(src[b][s][h][:], pos[b][s]) for B x S rows of H heads (in place when dst == src and the strides
+// agree).  A thread owns 4 consecutive frequency indices i4..i4+3 of one (b, s) row and walks the heads, so the sin / cos of
+// a position is computed once for all heads.  Strides (elements): *_bs between batch entries, *_ld between rows; pos_bs
+// between the position rows of consecutive batch entries.  The strided form lets the joint-attention assembly (scatter a
+// segment's q / k into the joint buffer, or gather its gradient back out) apply the rotation on the way instead of in a
+// separate in-place pass over the joint buffer.
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src,
+                                                   const int32_t* __restrict__ pos, const float* __restrict__ inv_freq, int B,
+                                                   int S, int64_t dst_bs, int64_t dst_ld, int64_t src_bs, int64_t src_ld,
+                                                   int64_t pos_bs, int H, int HD, int inverse) {
     const int tpr = HD >> 3;              // threads per row (HD/2 freqs, 4 per thread)
     const int rpb = 256 / tpr;            // rows per block
     const int rl = threadIdx.x / tpr;
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
     const int64_t nrows = (int64_t)B * S;
     for (int64_t r = (int64_t)blockIdx.x * rpb + rl; r < nrows; r += (int64_t)gridDim.x * rpb) {
         const int b = (int)(r / S), s = (int)(r - (int64_t)b * S);
-        const float p = (float)pos[r];
+        const float p = (float)pos[(int64_t)b * pos_bs + s];
         float c[4], sn[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -52,12 +57,11 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
             sn[e] = rbf(sinf(ang));
             if (inverse) sn[e] = -sn[e];
         }
-        bf16_t* xr = x + ((int64_t)b * s_ld + row0 + s) * (int64_t)H * HD;
+        const bf16_t* xr = src + (int64_t)b * src_bs + (int64_t)s * src_ld;
+        bf16_t* yr = dst + (int64_t)b * dst_bs + (int64_t)s * dst_ld;
         for (int h = 0; h < H; ++h) {
-            bf16_t* p1 = xr + h * HD + i4;
-            bf16_t* p2 = p1 + (HD >> 1);
-            bf16x4 a = *reinterpret_cast<const bf16x4*>(p1);
-            bf16x4 bq = *reinterpret_cast<const bf16x4*>(p2);
+            const bf16x4 a = *reinterpret_cast<const bf16x4*>(xr + h * HD + i4);
+            const bf16x4 bq = *reinterpret_cast<const bf16x4*>(xr + h * HD + i4 + (HD >> 1));
             bf16x4 o1, o2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, const
                 o1[e] = f2bf(rbf(x1 * c[e]) + rbf(-x2 * sn[e]));
                 o2[e] = f2bf(rbf(x2 * c[e]) + rbf(x1 * sn[e]));
             }
-            *reinterpret_cast<bf16x4*>(p1) = o1;
-            *reinterpret_cast<bf16x4*>(p2) = o2;
+            *reinterpret_cast<bf16x4*>(yr + h * HD + i4) = o1;
+            *reinterpret_cast<bf16x4*>(yr + h * HD + i4 + (HD >> 1)) = o2;
         }
     }
 }
@@ -538,9 +542,25 @@ KAI0_API int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_fre
     KAI0_REQUIRE(256 % (HD / 8) == 0, "kai0_rope_inplace: HD/8 must divide 256 (HD=%d)", HD);
     if (B * S <= 0) return 0;
     const int rpb = 256 / (HD / 8);
-    hipLaunchKernelGGL(rope_kernel, dim3(ew_grid((int64_t)B * S, rpb)), dim3(256), 0, S_(stream), (bf16_t*)x, pos,
-                       inv_freq, B, S, s_ld_rows, row0, H, HD, inverse);
+    const int64_t row = (int64_t)H * HD;
+    hipLaunchKernelGGL(rope_kernel, dim3(ew_grid((int64_t)B * S, rpb)), dim3(256), 0, S_(stream), (bf16_t*)x + row0 * row,
+                       (const bf16_t*)x + row0 * row, pos, inv_freq, B, S, s_ld_rows * row, row, s_ld_rows * row, row, (int64_t)S, H,
+                       HD, inverse);
     return kai0_check_launch("kai0_rope_inplace");
+}
+
+KAI0_API int kai0_rope_copy(const void* src, void* dst, const int32_t* pos, const float* inv_freq, int B, int S, int H, int HD,
+                            int64_t src_bs, int64_t src_ld, int64_t dst_bs, int64_t dst_ld, int64_t pos_bs, int inverse,
+                            kai0_stream_t stream) {
+    KAI0_REQUIRE(src && dst && pos && inv_freq, "kai0_rope_copy: null operand");
+    KAI0_REQUIRE(HD % 8 == 0 && HD >= 8 && HD <= 2048 && 256 % (HD / 8) == 0, "kai0_rope_copy: HD=%d unsupported", HD);
+    KAI0_REQUIRE(src_ld % 4 == 0 && dst_ld % 4 == 0 && src_bs % 4 == 0 && dst_bs % 4 == 0 && ((uintptr_t)src % 8) == 0 &&
+                     ((uintptr_t)dst % 8) == 0, "kai0_rope_copy: strides / bases must keep 8-byte alignment");
+    if (B * S <= 0) return 0;
+    const int rpb = 256 / (HD / 8);
+    hipLaunchKernelGGL(rope_kernel, dim3(ew_grid((int64_t)B * S, rpb)), dim3(256), 0, S_(stream), (bf16_t*)dst, (const bf16_t*)src,
+                       pos, inv_freq, B, S, dst_bs, dst_ld, src_bs, src_ld, pos_bs, H, HD, inverse);
+    return kai0_check_launch("kai0_rope_copy");
 }
 
 KAI0_API int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode, const int32_t* kcode, int B,

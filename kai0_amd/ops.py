@@ -1064,6 +1064,15 @@ def rope_(x, pos, inv_freq, Bn, S, s_ld, row0, H, HD, inverse=False):
               int(inverse), _stream())  # fmt: skip
 
 
+def rope_copy(src_t, dst_t, pos, inv_freq, Bn, S, H, HD, *, src, dst, pos_bs, pos_off=0, inverse=False):
+    """dst[b][dst_row0 + s] = rope(src[b][src_row0 + s], pos[b][pos_off + s]) (kai0_rope_copy).  `src` / `dst` =
+    (batch stride, row stride, first row) in elements / rows of the tensors' data pointers (which may be column slices)."""
+    sbs, sld, sr0 = src
+    dbs, dld, dr0 = dst
+    _lib.call("kai0_rope_copy", src_t.data_ptr() + 2 * sr0 * sld, dst_t.data_ptr() + 2 * dr0 * dld, pos.data_ptr() + 4 * pos_off,
+              inv_freq.data_ptr(), Bn, S, H, HD, sbs, sld, dbs, dld, pos_bs, int(inverse), _stream())  # fmt: skip
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -1144,12 +1153,12 @@ class JointAttentionFn(torch.autograd.Function):
         r0 = 0
         for i in range(nseg):
             Li = seg_lens[i]
-            _copy_rows(qs[i], q_all, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
-            _copy_rows(ks[i], k_all, Bn, Li, HD, Li * HD, 0, HD, S_ld * HD, r0, HD)
+            # q / k are rotated on their way into the joint buffers (one pass instead of copy + in-place RoPE)
+            rope_copy(qs[i], q_all, pos, inv_freq, Bn, Li, H, HD, src=(Li * H * HD, H * HD, 0), dst=(S_ld * H * HD, H * HD, r0),
+                      pos_bs=S, pos_off=r0)  # fmt: skip
+            rope_copy(ks[i], k_all, pos, inv_freq, Bn, Li, 1, HD, src=(Li * HD, HD, 0), dst=(S_ld * HD, HD, r0), pos_bs=S, pos_off=r0)
             _copy_rows(vs[i], v_all, Bn, Li, HD, Li * HD, 0, HD, S_ld * HD, r0, HD)
             r0 += Li
-        rope_(q_all, pos, inv_freq, Bn, S, S_ld, 0, H, HD)
-        rope_(k_all, pos, inv_freq, Bn, S, S_ld, 0, 1, HD)
         scale = HD**-0.5
         att, probs = mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, S, 0, S, S_ld, H, HD, scale)
         outs = []
@@ -1196,15 +1205,16 @@ class JointAttentionFn(torch.autograd.Function):
         dk_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(dscores, q_all, dk_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
              sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
-        rope_(dq_all, pos, inv_freq, Bn, S, S_ld, 0, H, HD, inverse=True)
-        rope_(dk_all, pos, inv_freq, Bn, S, S_ld, 0, 1, HD, inverse=True)
         grads = []
         r0 = 0
         for Li in seg_lens:
             W3 = (H + 2) * HD  # dq | dk | dv as column slices of one [Bn*Li, W3] buffer (see fused_columns)
             dq, dk, dv = fused_columns(Bn * Li, (H * HD, HD, HD), dev)
-            _copy_rows(dq_all, dq, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * W3, 0, W3)
-            _copy_rows(dk_all, dk, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
+            # the inverse rotation is applied while the segment's rows are gathered out of the joint gradient buffers
+            rope_copy(dq_all, dq, pos, inv_freq, Bn, Li, H, HD, src=(S_ld * H * HD, H * HD, r0), dst=(Li * W3, W3, 0), pos_bs=S,
+                      pos_off=r0, inverse=True)  # fmt: skip
+            rope_copy(dk_all, dk, pos, inv_freq, Bn, Li, 1, HD, src=(S_ld * HD, HD, r0), dst=(Li * W3, W3, 0), pos_bs=S, pos_off=r0,
+                      inverse=True)  # fmt: skip
             _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
             grads += [dq, dk, dv]
             r0 += Li
