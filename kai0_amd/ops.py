@@ -988,6 +988,7 @@ class EmbedFn(torch.autograd.Function):
         dst = getattr(ctx.table, "_kai0_grad_out", None)
         if dst is not None and dst.shape == (V, D) and dst.dtype == BF16:
             dtable = dst  # pre-zeroed slice of the trainer's flat gradient buffer
+            ctx.table._kai0_grad_accumulates = True  # the scatter-add needs it zeroed again before the next backward
         else:
             dtable = torch.zeros((V, D), dtype=BF16, device=dout.device)
         _lib.call("kai0_embed_grad", dout.data_ptr(), tokens.data_ptr(), dtable.data_ptr(), Bn, T, D, ctx.scale, T * D, 0,

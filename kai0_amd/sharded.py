@@ -83,6 +83,7 @@ class _Bucket:
         self.exp_avg_sq = torch.zeros(self.shard, dtype=F32, device=device)
         self.pending = len(params)
         self.arrived = set()
+        self.stale = set()  # parameters whose slice of flat_grad still holds the previous step's gradient
         self.work = None
 
 
@@ -186,6 +187,10 @@ class ShardedDataParallel:
         self.step_count += 1
         for b in self.buckets:
             if b.pending > 0:  # parameters that received no gradient this step contribute zeros
+                for p, o in zip(b.params, b.offsets):
+                    if id(p) in b.stale and id(p) not in b.arrived:  # ... not what an earlier step left in their slice
+                        b.flat_grad[o : o + p.numel()].zero_()
+                        b.stale.discard(id(p))
                 b.work = self._reduce_scatter_avg(b)
         for b in self.buckets:
             if b.work is not None:
@@ -208,10 +213,23 @@ class ShardedDataParallel:
         for w in works:
             if w is not None:
                 w.wait()
+        # Every gradient producer overwrites its parameter's whole slice, so the 7 GB of flat gradients are NOT cleared per
+        # step: a slice is zeroed only if its producer accumulates into it (the embedding scatter: `_kai0_grad_accumulates`)
+        # or, lazily in the next step(), if it holds an old gradient and no new one arrived.
+        full = os.environ.get("KAI0_ZERO_GRADS") == "full"  # diagnostics: clear everything, as before
         for b in self.buckets:
+            if full:
+                b.flat_grad.zero_()
+                b.stale.clear()
+            for p, o in zip(b.params, b.offsets):
+                if id(p) in b.arrived and not full:
+                    if getattr(p, "_kai0_grad_accumulates", False):
+                        b.flat_grad[o : o + p.numel()].zero_()
+                        b.stale.discard(id(p))
+                    else:
+                        b.stale.add(id(p))
             b.pending = len(b.params)
             b.arrived.clear()
-            b.flat_grad.zero_()
         return self._norm
 
     # ------------------------------------------------------------------------------------------ checkpointing

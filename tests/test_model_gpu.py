@@ -229,6 +229,24 @@ def test_trainer_flat_gradients_equal_plain_autograd(pair, ckpt):
     torch.cuda.synchronize()
     for (k, a), (_, b_) in zip(model.named_parameters(), ref.named_parameters()):
         assert rel(a, b_) < 1e-4, k
+    # second step: the flat gradient buffers are not cleared between steps (only accumulating producers' slices are, and
+    # slices that receive nothing are zeroed lazily) — a second backward must again equal plain autograd, bit for bit
+    ref.zero_grad(set_to_none=True)
+    kw2 = dict(noise=pair["noise"].to(dev).flip(0), time=pair["time"].to(dev).flip(0))
+    ref.load_state_dict(model.state_dict())
+    ref(*args, **kw2).mean().backward()
+    grads2 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    model(*args, **kw2).mean().backward()
+    torch.cuda.synchronize()
+    for b in eng.buckets:
+        for p, o in zip(b.params, b.offsets):
+            k = names[id(p)]
+            got = b.flat_grad[o : o + p.numel()].view(p.shape)
+            if k in grads2:
+                assert torch.equal(got, grads2[k]), k
+    norm = eng.step(1e-3)  # parameters without a gradient this step must enter the norm as zeros
+    want = torch.sqrt(sum(g.float().pow(2).sum() for g in grads2.values()))
+    assert abs(float(norm) - float(want)) <= 1e-3 * float(want)
 
 
 def test_state_dict_roundtrip_bit_exact(pair, tmp_path):
