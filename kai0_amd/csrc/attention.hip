@@ -57,7 +57,10 @@ struct AttnArgs {
 // NKS = number of 64-wide K sub-tiles (HD <= 64*NKS); VC = V tile columns (128 or 256); OMT = VC/16 output d-tiles
 // QT = 16-row query tiles per wave.  2: four waves per 128-row block (one per SIMD); 1: eight waves (two per SIMD), so that one
 // wave's MFMAs overlap the other's softmax VALU work and LDS reads — the block, its K / V tiles and LDS footprint are the same.
-template <int NKS, int VC, int QT>
+// OP > 0: single pass for Sk <= 64 * OP keys — all OP key tiles (K and V) are staged into LDS at once, the logits of the whole
+// row stay in registers (OP x 4 x QT accumulators), so Q K^T is computed once and there is no per-tile barrier; OP = 0: the
+// general two-pass form (pass 1: row max / sum, pass 2: recompute the logits, P, P V).
+template <int NKS, int VC, int QT, int OP = 0>
 __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int WAVES = 128 / (16 * QT);
     constexpr int OMT = VC / 16;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     constexpr int NVP = (64 / V_RPP) / WAVES;       // V DMA pieces per wave per tile
     static_assert(NKP >= 1 && NVP >= 1, "too many waves for this tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* pbuf_all = smem + 2 * STAGE;              // WAVES x [16 QT rows][64 keys] bf16 (P transposition scratch)
+    char* pbuf_all = smem + (OP > 0 ? OP : 2) * STAGE;  // WAVES x [16 QT rows][64 keys] bf16 (P transposition scratch)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,6 +195,127 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
         }
     };
 
+    f32x4 o[OMT][QT];
+#pragma unroll
+    for (int mt = 0; mt < OMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char* pbuf = pbuf_all + wave * (QT * 2048);
+    // one 64-key tile of the output side: final probabilities from the finished logits s (row max m, 1 / row sum inv_l),
+    // P written out, O^T += V^T P^T
+    auto emit_tile = [&](int kt, const char* tv, f32x4 (&s)[4][QT], const float (&m_run)[QT], const float (&inv_l)[QT]) {
+        // final probabilities, rounded to bf16 exactly once (what the reference multiplies V with)
+        bf16x4 pb[4][QT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (m_run[nt] > -INFINITY) ? __expf(s[mt][nt][r] - m_run[nt]) * inv_l[nt] : 0.f;
+                    pb[mt][nt][r] = f2bf(e);
+                }
+        // P tile -> global through a wave-private LDS transposition: write [16 QT q][64 keys] rows, read 16 B per lane
+        if (p.P != nullptr) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < QT; ++nt)
+                    *reinterpret_cast<bf16x4*>(pbuf + (nt * 16 + l15) * 128 + (mt * 16 + 4 * g) * 2) = pb[mt][nt];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // buffer stores with an out-of-range offset for the lanes that have nothing to write: the instruction is ALWAYS
+            // issued, so the wait at the end of the tile can count these 2 QT stores as the youngest memory operations and
+            // need not sit out their acknowledgement (vmcnt counts stores too; a plain vmcnt(0) there cost ~1 us per tile)
+#pragma unroll
+            for (int it = 0; it < 2 * QT; ++it) {
+                const int lr = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                const int r = row0 + lr, key = kt * 64 + c8;
+                const u32x4 pv = *reinterpret_cast<const u32x4*>(pbuf + lr * 128 + c8 * 2);
+                const uint32_t off = (r < p.rows && key < p.ldp) ? (uint32_t)(((int64_t)r * p.ldp + key) * 2) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(pv, p_rsrc, (int)off, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // O^T += V^T P^T : contraction over the 64 keys in two 32-key steps; step kk uses key blocks 2kk and 2kk+1, lane
+        // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pf[QT];
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
+            const int r_lo = kk * 32 + 4 * g + (l15 >> 2);   // key row this lane addresses for the transpose read
+            const int r_hi = r_lo + 16;
+#pragma unroll
+            for (int mt = 0; mt < OMT; ++mt) {
+                const int chunk = mt * 2 + ((l15 & 3) >> 1);
+                const int sub = (l15 & 1) * 8;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (LDS_PTR(bf16x4))(tv + r_lo * V_ROWB + ((chunk ^ ((r_lo & 7) << 1)) << 4) + sub));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (LDS_PTR(bf16x4))(tv + r_hi * V_ROWB + ((chunk ^ ((r_hi & 7) << 1)) << 4) + sub));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int nt = 0; nt < QT; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    if constexpr (OP > 0) {
+        // ============================ single pass (Sk <= 64 * OP): everything resident ================================
+#pragma unroll
+        for (int t = 0; t < OP; ++t)
+            if (t < ntiles) stage(t, t, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        f32x4 sall[OP][4][QT];
+        float m_run[QT], inv_l[QT];
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) m_run[nt] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < OP; ++t) {
+            if (t < ntiles) {
+                int kc[4][4];
+                load_kcodes(t, kc);
+                logits(smem + t * STAGE, sall[t]);
+                finish_logits(t, sall[t], kc);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < QT; ++nt) sall[t][mt][nt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m_run[nt] = fmaxf(m_run[nt], sall[t][mt][nt][r]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) {
+            float m = m_run[nt];
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+            if (m > -INFINITY) {
+#pragma unroll
+                for (int t = 0; t < OP; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) l += __expf(sall[t][mt][nt][r] - m);
+            }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            m_run[nt] = m;
+            inv_l[nt] = l > 0.f ? 1.0f / l : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < OP; ++t)
+            if (t < ntiles) emit_tile(t, smem + t * STAGE + K_BYTES, sall[t], m_run, inv_l);
+    } else {
     // ================================ pass 1: row max and row sum =====================================================
     float m_run[QT], l_run[QT];
 #pragma unroll
@@ -245,12 +369,6 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     }
 
     // ================================ pass 2: P and O = P V ===========================================================
-    f32x4 o[OMT][QT];
-#pragma unroll
-    for (int mt = 0; mt < OMT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < QT; ++nt) o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    char* pbuf = pbuf_all + wave * (QT * 2048);
     stage(0, 0, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -258,72 +376,17 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
         const int buf = kt & 1;
         if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, true);
         const char* tk = smem + buf * STAGE;
-        const char* tv = tk + K_BYTES;
         int kc[4][4];
         load_kcodes(kt, kc);
         f32x4 s[4][QT];
         logits(tk, s);
         finish_logits(kt, s, kc);
-        // final probabilities, rounded to bf16 exactly once (what the reference multiplies V with)
-        bf16x4 pb[4][QT];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < QT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = (m_run[nt] > -INFINITY) ? __expf(s[mt][nt][r] - m_run[nt]) * inv_l[nt] : 0.f;
-                    pb[mt][nt][r] = f2bf(e);
-                }
-        // P tile -> global through a wave-private LDS transposition: write [32 q][64 keys] rows, read 16 B per lane
-        if (p.P != nullptr) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < QT; ++nt)
-                    *reinterpret_cast<bf16x4*>(pbuf + (nt * 16 + l15) * 128 + (mt * 16 + 4 * g) * 2) = pb[mt][nt];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            // buffer stores with an out-of-range offset for the lanes that have nothing to write: the instruction is ALWAYS
-            // issued, so the wait at the end of the tile can count these 2 QT stores as the youngest memory operations and
-            // need not sit out their acknowledgement (vmcnt counts stores too; a plain vmcnt(0) there cost ~1 us per tile)
-#pragma unroll
-            for (int it = 0; it < 2 * QT; ++it) {
-                const int lr = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-                const int r = row0 + lr, key = kt * 64 + c8;
-                const u32x4 pv = *reinterpret_cast<const u32x4*>(pbuf + lr * 128 + c8 * 2);
-                const uint32_t off = (r < p.rows && key < p.ldp) ? (uint32_t)(((int64_t)r * p.ldp + key) * 2) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(pv, p_rsrc, (int)off, 0, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // O^T += V^T P^T : contraction over the 64 keys in two 32-key steps; step kk uses key blocks 2kk and 2kk+1, lane
-        // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 pf[QT];
-#pragma unroll
-            for (int nt = 0; nt < QT; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
-            const int r_lo = kk * 32 + 4 * g + (l15 >> 2);   // key row this lane addresses for the transpose read
-            const int r_hi = r_lo + 16;
-#pragma unroll
-            for (int mt = 0; mt < OMT; ++mt) {
-                const int chunk = mt * 2 + ((l15 & 3) >> 1);
-                const int sub = (l15 & 1) * 8;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (LDS_PTR(bf16x4))(tv + r_lo * V_ROWB + ((chunk ^ ((r_lo & 7) << 1)) << 4) + sub));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (LDS_PTR(bf16x4))(tv + r_hi * V_ROWB + ((chunk ^ ((r_hi & 7) << 1)) << 4) + sub));
-                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int nt = 0; nt < QT; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
-            }
-        }
+        emit_tile(kt, tk + K_BYTES, s, m_run, inv_l);
         // the DMA of tile kt+1 (issued at the top of this iteration) must have landed; the P stores issued after it may fly
         if (p.P != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
+    }
     }
     // zero the padding columns [64*ntiles, ldp) of P (none when ldp <= 64*ntiles) — the tiles above already wrote
     // zeros for keys in [Sk, 64*ntiles)
@@ -374,11 +437,11 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     const int batch = d->batch > 0 ? d->batch : 1;
     dim3 grid((d->rows + 127) / 128, batch, 1);
     hipStream_t s = (hipStream_t)stream;
-#define KAI0_ATTN_LAUNCH(NKS, VC, QT)                                                                              \
+#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP)                                                                          \
     do {                                                                                                          \
-        constexpr int LDS = 2 * (NKS * 8192 + 64 * VC * 2) + 4 * 4096;                                            \
+        constexpr int LDS = (OP > 0 ? OP : 2) * (NKS * 8192 + 64 * VC * 2) + 4 * 4096;                            \
         static bool attr_set = false;                                                                             \
-        auto kern = attn_fwd_kernel<NKS, VC, QT>;                                                                 \
+        auto kern = attn_fwd_kernel<NKS, VC, QT, OP>;                                                             \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             KAI0_REQUIRE(e == hipSuccess, "kai0_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
@@ -386,14 +449,18 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
         }                                                                                                         \
         hipLaunchKernelGGL(kern, grid, dim3(128 / (16 * QT) * 64), LDS, s, p);                                    \
     } while (0)
-    // KAI0_ATTN_QT=2: the former four-wave blocks (diagnostics)
+    // KAI0_ATTN_QT=2: the former four-wave blocks; KAI0_ATTN_ONEPASS=0: always two passes (diagnostics)
     static const int qt = [] { const char* e = getenv("KAI0_ATTN_QT"); return e ? atoi(e) : 1; }();
+    static const int onepass = [] { const char* e = getenv("KAI0_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
     if (d->HD <= 128) {
-        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2);
-        else KAI0_ATTN_LAUNCH(2, 128, 1);
+        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0);
+        // 256 keys = 4 resident tiles (144 KiB, one block per CU): wins when the grid is at most a round or two of the chip
+        // (B = 1 inference: 26 -> 19 us); with thousands of blocks the two-pass form's two 80-KiB blocks per CU are as fast
+        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4);
+        else KAI0_ATTN_LAUNCH(2, 128, 1, 0);
     } else {
-        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2);
-        else KAI0_ATTN_LAUNCH(4, 256, 1);
+        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0);
+        else KAI0_ATTN_LAUNCH(4, 256, 1, 0);
     }
 #undef KAI0_ATTN_LAUNCH
     return kai0_check_launch("kai0_attn_fwd");
