@@ -40,22 +40,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int kbeg = blockIdx.z * k_chunk;
     const int kstop = min(K, kbeg + k_chunk);
     const bool split = gridDim.z > 1;
-    for (int k0 = kbeg; k0 < kstop; k0 += FBK) {
+    // Global -> register -> LDS staging, one 64x16 tile of each operand per K-step, software-pipelined: the loads of step
+    // t+1 are in flight while step t's MFMAs run.  Operands whose contraction index is the memory-fastest one (forward:
+    // x [M][K] and W [N][K]) are read with one 16-B load per thread (thread -> row tid/4, k (tid%4)*4..+3) when rows are
+    // 16-B aligned; everything else keeps the strided scalar loads (thread-fastest index = memory-fastest index).
+    const bool a_vec = a_kfast && ((sam & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool b_vec = b_kfast && ((sbn & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    const int vr = tid >> 2, vk = (tid & 3) * 4;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        if (a_vec) {
+            const bool rok = m0 + vr < M;
+            const float* ap = A + (int64_t)(m0 + vr) * sam + (k0 + vk);
+            if (rok && k0 + vk + 3 < kstop) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+                ra[0] = v[0]; ra[1] = v[1]; ra[2] = v[2]; ra[3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[e] = (rok && k0 + vk + e < kstop) ? ap[e] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = e * 256 + tid;
+                int m, k;
+                if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+                ra[e] = (m0 + m < M && k0 + k < kstop) ? A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak] : 0.f;
+            }
+        }
+        if (b_vec) {
+            const bool rok = n0 + vr < N;
+            const float* bp = B + (int64_t)(n0 + vr) * sbn + (k0 + vk);
+            if (rok && k0 + vk + 3 < kstop) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp);
+                rb[0] = v[0]; rb[1] = v[1]; rb[2] = v[2]; rb[3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = (rok && k0 + vk + e < kstop) ? bp[e] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = e * 256 + tid;
+                int n, kb;
+                if (b_kfast) { kb = idx & 15; n = idx >> 4; } else { n = idx & 63; kb = idx >> 6; }
+                rb[e] = (n0 + n < N && k0 + kb < kstop) ? B[(int64_t)(k0 + kb) * sbk + (int64_t)(n0 + n) * sbn] : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int idx = e * 256 + tid;  // 0..1023
-            int m, k;
-            if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
-            float v = 0.f;
-            if (m0 + m < M && k0 + k < kstop) v = A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak];
-            As[k * PITCH + m] = v;
-            int n, kb;
-            if (b_kfast) { kb = idx & 15; n = idx >> 4; } else { n = idx & 63; kb = idx >> 6; }
-            float w = 0.f;
-            if (n0 + n < N && k0 + kb < kstop) w = B[(int64_t)(k0 + kb) * sbk + (int64_t)(n0 + n) * sbn];
-            Bs[kb * PITCH + n] = w;
+            const int idx = e * 256 + tid;
+            if (a_vec) {
+                As[(vk + e) * PITCH + vr] = ra[e];
+            } else {
+                int m, k;
+                if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+                As[k * PITCH + m] = ra[e];
+            }
+            if (b_vec) {
+                Bs[(vk + e) * PITCH + vr] = rb[e];
+            } else {
+                int n, kb;
+                if (b_kfast) { kb = idx & 15; n = idx >> 4; } else { n = idx & 63; kb = idx >> 6; }
+                Bs[kb * PITCH + n] = rb[e];
+            }
         }
+    };
+    if (kbeg < kstop) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kstop; k0 += FBK) {
+        commit();
         __syncthreads();
+        if (k0 + FBK < kstop) fetch(k0 + FBK);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             float a[2], b[2];
