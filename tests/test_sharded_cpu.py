@@ -108,6 +108,42 @@ def test_sharded_engine_world1_equals_reference():
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-5)
 
 
+def test_flat_gradients_of_parameters_without_a_new_gradient_count_as_zero(monkeypatch):
+    """The flat gradient buffers are not cleared after a step (producers overwrite their slices): a parameter that got a
+    gradient in step t but none in step t+1 must enter step t+1 as zero, not with its old gradient.  Reference: the same
+    engine with the full clear after every step (KAI0_ZERO_GRADS=full)."""
+    from kai0_amd.sharded import ShardedDataParallel
+
+    class TwoBranch(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.a, self.b = torch.nn.Linear(6, 6), torch.nn.Linear(6, 6)
+
+        def forward(self, x, use_b):
+            return self.a(x).sum() + (self.b(x).pow(2).sum() if use_b else 0.0)
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv("KAI0_ZERO_GRADS", mode)
+        else:
+            monkeypatch.delenv("KAI0_ZERO_GRADS", raising=False)
+        m = TwoBranch()
+        eng = ShardedDataParallel(m.parameters(), world_size=1, rank=0, ops=TorchShardOps(), weight_decay=0.0, max_grad_norm=10.0,
+                                  bucket_bytes=64)  # fmt: skip
+        norms = []
+        x = torch.linspace(-1, 1, 12).reshape(2, 6)
+        for use_b in (True, False, False, True):
+            m(x, use_b).backward()
+            norms.append(float(eng.step(1e-2)))
+        return [p.detach().clone() for p in m.parameters()], norms
+
+    lazy, n_lazy = run(None)
+    full, n_full = run("full")
+    assert n_lazy == n_full and n_lazy[1] < n_lazy[0]  # steps 2, 3 see no gradient for branch b
+    assert all(torch.equal(a, b) for a, b in zip(lazy, full))
+
+
 def test_checkpoint_helpers_roundtrip_with_flat_buffers(tmp_path):
     """Parameters that are views into flat buffers (as in the trainer) still save/load bit-exactly, tied weights once."""
     from safetensors.torch import load_file
