@@ -156,3 +156,40 @@ def test_backward_at_full_size_against_closed_form_and_one_step_lowers_the_loss(
         l1 = float(tr.train_step(obs, a, noise=n, time=t))
     assert l1 < l0, (l0, l1)
     m.eval()
+
+
+def test_advantage_estimator_with_six_images_at_full_size(full):
+    """Stage-Advantage estimator on the real architecture: two timesteps x three cameras (prefix 6 x 256 + 200 = 1736 tokens, a
+    sequence of 1786 — the longest attention shape of the path), value head, weighted loss, backward, sample_values."""
+    from kai0_amd.config import AdvantageEstimatorConfig
+    from kai0_amd.model import AdvantageEstimator
+
+    dev, obs, a, n, t = (full[k] for k in ("dev", "obs", "actions", "noise", "time"))
+    torch.manual_seed(1)
+    with torch.device(dev):
+        m = AdvantageEstimator(AdvantageEstimatorConfig(loss_value_weight=1.0, loss_action_weight=0.5))
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "dense.weight" in k:
+                p.normal_(0.0, 0.02)
+    o = _take(obs, 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    for name in ("base_-1_rgb", "left_wrist_-1_rgb", "right_wrist_-1_rgb"):
+        o.images[name] = torch.rand(1, 3, 224, 224, generator=g, device=dev) * 2 - 1
+        o.image_masks[name] = torch.ones(1, dtype=torch.bool, device=dev)
+    o.progress = torch.tensor([0.4], device=dev)
+    m.train()
+    loss, aux = m(o, a[:1], noise=n[:1], time=t[:1], return_loss_dict=True)
+    assert loss.shape == (1, 50) and torch.isfinite(loss).all() and torch.isfinite(aux["loss_value"])
+    loss.mean().backward()
+    gv = m.value_head[4].weight.grad
+    gq = m.paligemma_with_expert.paligemma.model.language_model.layers[3].self_attn.q_proj.weight.grad
+    assert gv is not None and torch.isfinite(gv).all() and float(gv.abs().sum()) > 0
+    assert gq is not None and torch.isfinite(gq.float()).all() and float(gq.float().abs().sum()) > 0
+    m.eval()
+    v1 = m.sample_values(dev, o, noise=n[:1], time=t[:1])
+    v2 = m.sample_values(dev, o, noise=n[:1], time=t[:1])
+    assert v1.shape == (1, 1) and torch.equal(v1, v2) and float(v1.abs()) < 1.0
+    # the history frames matter: other pixels at t = -1 change the value
+    o.images["base_-1_rgb"] = torch.rand(1, 3, 224, 224, generator=g, device=dev) * 2 - 1
+    assert not torch.equal(m.sample_values(dev, o, noise=n[:1], time=t[:1]), v1)
