@@ -9,11 +9,16 @@ architecture (3.617 B stored / 3.353 B used parameters).  A step = augmentation 
 clip + fused AdamW over every parameter: nothing is skipped inside the timed region.
 
 Extra objects on the same line:
-  roofline     — the dominant kernel (gemm_bf16_kernel): achieved = algorithmic FLOPs (14.04 TFLOP per
-                 sample per train step) / summed GEMM launch durations, measured with HIP events on the launch stream
-                 inside the timed region; peak = 2.5 PFLOP/s dense bf16 MFMA.
-  cpu_baseline — the CPU oracle (a port: the reference cannot be imported here) timed on the host cores on a bounded
-                 sample of the same workload (see `sample`).
+  roofline     — the dominant kernel (gemm_bf16_kernel): achieved = algorithmic FLOPs (2 M N K of every launch; SURVEY.md
+                 §8d: 14.04 TFLOP per sample per train step) / summed GEMM launch durations, measured with HIP events on
+                 the launch stream over two further identical steps run right after the timed region (inside it the event
+                 records cost ~10 ms per step); peak = 2.5 PFLOP/s dense bf16 MFMA.
+  inference    — p50 of one B = 1 action chunk (SigLIP + prefix pass + 10 Euler steps, hipGraph replay, chunk copied to the
+                 host), its three stage times, and the chunk against its floors: 5.02 TFLOP of MFMA work and 9.0 GB of
+                 weight traffic.
+  cpu_baseline — the CPU oracle (a port: the reference cannot be imported here) timed on the host cores on the REAL
+                 network (all 18 joint + 27 SigLIP layers, full widths): one sample forward + backward, plus clip + AdamW
+                 over every parameter; see `sample`.
 """
 
 from __future__ import annotations
@@ -117,56 +122,119 @@ class GemmTimer:
                  "tflops": v[2] / v[1] / 1e9} for k, v in rows]
 
 
-def cpu_baseline(budget_s: float = 20.0):
-    """The CPU oracle (a port — the reference cannot be imported here) on the host cores: one sample, forward +
-    backward through a full-width slice of the network (2 of 27 SigLIP layers x 3 cameras, 1 of 18 joint
-    Gemma-2B/expert layers, vocab 2048), fp32 (bf16 matmuls are emulated on hosts without AMX and would understate the
-    CPU); the time is scaled to the full depth by FLOP share.  The full 3.6 B-parameter oracle needs minutes just to
-    initialise on CPU, which would not fit the default run."""
-    import copy
+def _oracle_full_depth(O):
+    """The full-depth, full-width oracle (fp32), built without the minutes of nn.init / seeded randn a 2.8 B-parameter CPU
+    model costs: allocated on the meta device, materialised, and filled from one N(0, 0.02) block tiled over every matrix
+    (values only need to be of the right scale for a timing).  vocab 2048 (synthetic prompt ids < 2048): the 0.53 B-row
+    embedding table and the dead expert lm_head carry no FLOPs and are left out of the host's memory."""
+    cfg = O.OracleConfig(dtype="float32", vocab_size=2048)
+    with torch.device("meta"):
+        model = O.OraclePI0(cfg)
+    model.to_empty(device="cpu")
+    block = torch.randn(1 << 22, generator=torch.Generator().manual_seed(0)) * 0.02
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "norm" in n and "dense" not in n:
+                p.fill_(1.0 if "vision" in n else 0.0)  # LayerNorm weight 1 / bias below; plain RMSNorm weight 0 (checkpoint-like)
+            else:
+                flat = p.view(-1)
+                for lo in range(0, flat.numel(), block.numel()):
+                    hi = min(flat.numel(), lo + block.numel())
+                    flat[lo:hi].copy_(block[: hi - lo])
+        for mod in model.modules():  # non-persistent buffers are not materialised by to_empty
+            if isinstance(getattr(mod, "inv_freq", None), torch.Tensor):
+                mod.inv_freq = O.rope_inv_freq(mod.inv_freq.numel() * 2)
+            if isinstance(mod, O.SiglipVisionEmbeddings):
+                mod.position_ids = torch.arange(mod.num_patches).expand((1, -1))
+    return model, cfg
+
+
+def cpu_baseline(batch: int = 32):
+    """The CPU oracle (kind "port": the reference cannot be imported in this image) timed on the host cores on the REAL
+    network: one sample through forward + backward of all 27 SigLIP x 3 cameras and 18 joint Gemma-2B / expert layers in fp32
+    (bf16 matmuls are emulated on hosts without AMX and would understate the CPU), then `clip_grad_norm_` + `AdamW.step()`
+    (the reference trainer's calls, train_pytorch.py:557-561) over every parameter.  A training step of the benchmarked
+    workload (batch 32) = 32 x the per-sample forward/backward + one optimizer pass: value = 32 / (32 t_fb + t_opt).
+    Bounded: one warm pass + one timed pass (~10-25 s each on a 64-core host); nothing is extrapolated across layers."""
+    import psutil
 
     from oracle import pi0_oracle as O
 
-    n_sig, n_joint = 2, 1
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    vlm, exp = copy.copy(O.get_gemma_config("gemma_2b")), copy.copy(O.get_gemma_config("gemma_300m"))
-    vlm.depth = exp.depth = n_joint
-    orig = O.get_gemma_config
-    O.get_gemma_config = lambda v: vlm if v == "gemma_2b" else exp
-    try:
-        cfg = O.OracleConfig(dtype="float32", vocab_size=2048, siglip=O.SiglipCfg(num_layers=n_sig))
-        model = O.OraclePI0(cfg)
-    finally:
-        O.get_gemma_config = orig
-    O.synthetic_weights_(model, seed=0)
+    t0 = time.time()
+    model, cfg = _oracle_full_depth(O)
+    init_s = time.time() - t0
     obs, actions, noise, t = O.synthetic_batch(cfg, 1, seed=0)
     times = []
-    t_start = time.time()
-    while len(times) < 4 and (not times or time.time() - t_start + times[-1] < budget_s):
+    for _ in range(2):  # the first pass also pages the 11 GB of weights in
         model.zero_grad(set_to_none=True)
         t0 = time.time()
         model(obs, actions, noise, t).mean().backward()
         times.append(time.time() - t0)
-    per_slice = min(times)
-    # FLOP share of the slice (SURVEY §8d, per-sample forward TFLOP): SigLIP 0.661 over 27 layers (3 cameras included),
-    # joint layers (3.837 + 0.153 + 0.031) over 18
-    slice_tf = 0.661 * n_sig / 27 + (3.837 + 0.153 + 0.031) * n_joint / 18
-    full_tf = 4.68
-    est_step_s = per_slice * full_tf / slice_tf
+        if times[-1] > 45.0:
+            break
+    t_fb = min(times)
+    # optimizer: every parameter that received a gradient, if the host has room for the two moment buffers (8 B/param);
+    # otherwise the expert tower + SigLIP only, scaled by parameter count (the update is linear in it)
+    params = [p for p in model.parameters() if p.grad is not None]
+    n_all = sum(p.numel() for p in params)
+    subset = params
+    if psutil.virtual_memory().available < 12 * n_all + (16 << 30):
+        subset = [p for n, p in model.named_parameters() if p.grad is not None and "language_model" not in n]
+    n_sub = sum(p.numel() for p in subset)
+    opt = torch.optim.AdamW(subset, lr=2.5e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-10, foreach=False)
+    t0 = time.time()
+    torch.nn.utils.clip_grad_norm_(subset, 1.0, foreach=False)
+    opt.step()
+    t_opt = (time.time() - t0) * n_all / n_sub
+    step_s = batch * t_fb + t_opt
     return {
-        "value": 1.0 / est_step_s,
+        "value": batch / step_s,
         "unit": "samples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"1 sample fwd+bwd (no optimizer), fp32 oracle, full-width slice: {n_sig}/27 SigLIP x3 cams + "
-        f"{n_joint}/18 joint layers = {per_slice:.2f} s (best of {len(times)}), scaled by FLOP share "
-        f"{slice_tf / full_tf:.3f} to {est_step_s:.1f} s/sample",
+        "fwd_bwd_s_per_sample": t_fb,
+        "optimizer_s": t_opt,
+        "init_s": init_s,
+        "sample": f"fp32 oracle, full depth and width (18 joint + 27 SigLIP layers x 3 cameras, {n_all / 1e9:.2f} B parameters with "
+        f"gradients; vocab 2048): 1 sample forward+backward = {t_fb:.2f} s (best of {len(times)}: "
+        f"{', '.join(f'{x:.1f}' for x in times)}), clip_grad_norm_ + AdamW.step over "
+        f"{'all' if n_sub == n_all else f'{n_sub / 1e9:.2f} B (scaled by count to all)'} parameters = {t_opt:.2f} s; "
+        f"a batch-{batch} step = {batch} x {t_fb:.2f} + {t_opt:.2f} = {step_s:.1f} s; model construction {init_s:.1f} s not included",
     }
 
 
-def measure_latency(model, cfg, device, iters: int = 30):
-    """p50 of Policy-level model time for one action chunk at B=1 (prefix pass + 10 denoise steps, hipGraph)."""
+INFER_TFLOP = 5.02  # SURVEY.md §8d: prefix pass 4.635 TFLOP + 10 x 38.9 GFLOP
+INFER_GB = 9.0      # SURVEY.md §8d: 4.79 GB prefix weights + 10 x 0.42 GB expert weights (bf16, modulations precomputed)
+HBM_PEAK_TBS = 8.0  # MI355X_MICROARCH.md: HBM3E spec
+
+
+def _graph_time_ms(fn, iters: int = 20):
+    """p50 wall time of `fn` replayed from its own hipGraph (device time: events on the replay stream)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        e.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def measure_latency(model, cfg, device, iters: int = 40):
+    """One B = 1 action chunk (prefix pass + 10 denoise steps, hipGraph): p50 of the Policy-level model time (replay + the
+    chunk's copy to the host, policy.py:114-118), and the three stages timed as graphs of their own."""
     model.eval()
     obs, _ = synthetic_batch(cfg, 1, seed=123, device=device)
     noise = torch.randn(1, cfg.action_horizon, cfg.action_dim, device=device)
@@ -180,8 +248,30 @@ def measure_latency(model, cfg, device, iters: int = 30):
         out.cpu()  # Policy.infer moves the chunk to the host (policy.py:114-118)
         ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
+    p50 = ts[len(ts) // 2]
+    res = {"p50_ms": p50, "min_ms": ts[0], "p90_ms": ts[int(len(ts) * 0.9)]}
+    try:
+        eng = model._engine
+        si = eng._static_in
+        with torch.no_grad():
+            t_sig = _graph_time_ms(lambda: eng._siglip(torch.cat(si["images"], dim=0)))
+            t_pre = _graph_time_ms(lambda: eng._prefix_pass(si["images"], si["img_masks"], si["lang_tokens"], si["lang_masks"]))
+            t_all = _graph_time_ms(lambda: eng._run(si["images"], si["img_masks"], si["lang_tokens"], si["lang_masks"], si["noise"], 10))
+        res["stages_ms"] = {"siglip": t_sig, "prefix": t_pre - t_sig, "denoise_10_steps": t_all - t_pre, "graph_total": t_all}
+    except Exception as e:  # noqa: BLE001 - the stage split is diagnostics; the p50 above stands on its own
+        res["stages_error"] = repr(e)[:200]
+    mfma_floor = INFER_TFLOP / MFMA_BF16_PEAK_TFLOPS * 1e3
+    hbm_floor = INFER_GB / (HBM_PEAK_TBS * 1e3) * 1e3
+    res.update({
+        "algorithmic_tflop": INFER_TFLOP, "algorithmic_gb": INFER_GB,
+        "mfma_floor_ms": mfma_floor, "hbm_floor_ms": hbm_floor,
+        "bound": "mfma" if mfma_floor >= hbm_floor else "hbm",
+        "achieved_tflops": INFER_TFLOP / (p50 / 1e3), "achieved_gbs": INFER_GB / (p50 / 1e3),
+        "frac": max(mfma_floor, hbm_floor) / p50,
+        "target_ms": 15.0,
+    })
     model.train()
-    return ts[len(ts) // 2]
+    return res
 
 
 def main():
@@ -329,9 +419,10 @@ def main():
         if world == 1 and not args.no_latency:
             del trainer
             torch.cuda.empty_cache()
-            out["p50_action_chunk_ms"] = measure_latency(model, cfg, device)
+            out["inference"] = measure_latency(model, cfg, device)
+            out["p50_action_chunk_ms"] = out["inference"]["p50_ms"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(B)
         try:  # whatever native libraries still hold in C stdio buffers goes out first: the JSON line must be the last one
             import ctypes
 

@@ -34,6 +34,7 @@ class AgilexInputs:
     action_dim: int
     model_type: object = "pi0"
     mask_state: bool = False  # feed an all-zero state
+    filter_state_glitches: ClassVar[bool] = True
 
     required_rename_map: ClassVar[dict] = {"top_head": "base_0_rgb", "hand_left": "left_wrist_0_rgb",
                                            "hand_right": "right_wrist_0_rgb"}  # fmt: skip
@@ -63,7 +64,9 @@ class AgilexInputs:
                 masks[self.all_rename_map[cam]] = np.True_
             elif cam in self.EXPECTED_CAMERAS:
                 raise ValueError(f"Camera {cam} not found in data")
-        state = _clip_glitches(transforms.pad_to_dim(data["state"], self.action_dim).squeeze())
+        state = transforms.pad_to_dim(data["state"], self.action_dim).squeeze()
+        if self.filter_state_glitches:
+            state = _clip_glitches(state)
         out = {"image": images, "image_mask": masks, "state": np.zeros_like(state) if self.mask_state else state}
         if "actions" in data:
             actions = _clip_glitches(transforms.pad_to_dim(data["actions"], self.action_dim))
@@ -97,3 +100,16 @@ class AgilexOutputs:
 
     def __call__(self, data: dict) -> dict:
         return {"actions": np.asarray(data["actions"][:, :14])}
+
+
+@dataclasses.dataclass(frozen=True)
+class ARXInputs(AgilexInputs):
+    """`src/openpi/policies/arx_policy.py`: the ARX platform (HangCloth) — the Agilex mapping without the state glitch filter
+    (the action filter stays, arx_policy.py:100-103)."""
+
+    filter_state_glitches: ClassVar[bool] = False
+
+
+@dataclasses.dataclass(frozen=True)
+class ARXOutputs(AgilexOutputs):
+    pass

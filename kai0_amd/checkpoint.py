@@ -32,7 +32,9 @@ def save_model_safetensors(model: torch.nn.Module, path: str) -> None:
 def load_model_safetensors(model: torch.nn.Module, path: str, strict: bool = True) -> None:
     sd = load_file(path)
     missing, unexpected = model.load_state_dict(sd, strict=False)
-    aliases = {a for names in _tied_groups(model) for a in names[1:]} | {names[0] for names in _tied_groups(model) if len(names) > 1}
-    missing = [k for k in missing if k not in aliases]
+    # a missing name is forgiven only if it is tied to a tensor the file DID contain (what safetensors.torch.load_model
+    # forgives: the aliases save_model dropped); a file with no member of a tied group leaves that weight unloaded -> error
+    forgiven = {n for names in _tied_groups(model) if any(m in sd for m in names) for n in names}
+    missing = [k for k in missing if k not in forgiven]
     if strict and (missing or unexpected):
         raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {list(unexpected)}")

@@ -73,6 +73,29 @@ class Pi0Config:
         if self.discrete_state_input is None:
             self.discrete_state_input = self.pi05
 
+    @property
+    def model_type(self) -> str:
+        """`ModelType` value (models/model.py:27-35; pi0_config.py:43-47)."""
+        return "pi05" if self.pi05 else "pi0"
+
+    def _model_class(self):
+        from .model import PI0Pytorch
+
+        return PI0Pytorch
+
+    def load_pytorch(self, train_config, weight_path: str):
+        """`BaseModelConfig.load_pytorch` (models/model.py:276-280): build the torch-protocol model from `train_config.model`
+        and load `model.safetensors` (strict, tied `lm_head` forgiven as `safetensors.torch.load_model` does).  The weights
+        are read before any trainer / inference engine exists, as both require (kai0_amd.sharded / kai0_amd.infer)."""
+        import logging
+
+        from .checkpoint import load_model_safetensors
+
+        logging.getLogger("kai0_amd").info(f"train_config: {train_config}")
+        model = train_config.model._model_class()(train_config.model)
+        load_model_safetensors(model, weight_path)
+        return model
+
 
 @dataclasses.dataclass
 class AdvantageEstimatorConfig(Pi0Config):
@@ -81,3 +104,8 @@ class AdvantageEstimatorConfig(Pi0Config):
 
     loss_action_weight: float = 1.0
     loss_value_weight: float = 1.0
+
+    def _model_class(self):
+        from .model import AdvantageEstimator
+
+        return AdvantageEstimator

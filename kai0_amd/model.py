@@ -259,6 +259,16 @@ def build_mask_codes(pad_masks: torch.Tensor, att_masks: torch.Tensor):
     return qcode, kcode, pos
 
 
+class _NoUnitHooks:
+    """Default `unit_hooks`: the model announces each sharding unit (kai0_amd.sharded) to nobody."""
+
+    def pre_forward(self, unit: str):
+        pass
+
+    def post_forward(self, unit: str, *tensors):
+        return tensors
+
+
 class PaliGemmaWithExpertModel(nn.Module):
     """Parameter tree + kernels-backed compute of gemma_pytorch.py:12-281."""
 
@@ -274,6 +284,8 @@ class PaliGemmaWithExpertModel(nn.Module):
         self.paligemma = PaliGemmaForConditionalGeneration(vlm_config, vocab, self.siglip_cfg)
         self.gemma_expert = GemmaForCausalLM(action_expert_config, vocab, use_adarms[1])
         self.remat = False
+        # the sharded trainer hangs its parameter gather / release logic here (Trainer -> PI0Pytorch.set_unit_hooks)
+        self.unit_hooks = _NoUnitHooks()
         self.to_bfloat16_for_selected_params(precision)
 
     def to_bfloat16_for_selected_params(self, precision: str = "bfloat16"):
@@ -299,8 +311,11 @@ class PaliGemmaWithExpertModel(nn.Module):
         S = vt.embeddings.num_patches
         NH, HD = sc.num_heads, sc.hidden_size // sc.num_heads
         emb = vt.embeddings
+        hk = self.unit_hooks
+        hk.pre_forward("siglip.embed")
         x = ops.patch_embed(image.contiguous(), emb.patch_embedding.weight, emb.patch_embedding.bias,
                             emb.position_embedding.weight, sc.patch_size)  # fmt: skip
+        (x,) = hk.post_forward("siglip.embed", x)
 
         def layer_fn(x, layer):
             x, h = ops.layernorm_res(x, layer.layer_norm1.weight, layer.layer_norm1.bias, layer.layer_norm1.eps)
@@ -313,8 +328,11 @@ class PaliGemmaWithExpertModel(nn.Module):
             m = layer.mlp
             return ops.gelu_mlp(h, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, residual=x)
 
-        for layer in vt.encoder.layers:
+        for l, layer in enumerate(vt.encoder.layers):
+            hk.pre_forward(f"siglip.{l}")
             x = self._maybe_remat(layer_fn, x, layer)
+            (x,) = hk.post_forward(f"siglip.{l}", x)
+        hk.pre_forward("prefix")  # post-LN, projector, token / action / time embeddings: closed by PI0Pytorch._trunk
         x = ops.layernorm(x, vt.post_layernorm.weight, vt.post_layernorm.bias, vt.post_layernorm.eps)
         x = _lin(x, self.paligemma.model.multi_modal_projector.linear)
         return x.view(n, S, -1)
@@ -360,8 +378,12 @@ class PaliGemmaWithExpertModel(nn.Module):
             return xp, xs
 
         xp, xs = prefix, suffix
-        for lp, le in zip(lm.layers, ex.layers, strict=True):
+        hk = self.unit_hooks
+        for l, (lp, le) in enumerate(zip(lm.layers, ex.layers, strict=True)):
+            hk.pre_forward(f"joint.{l}")
             xp, xs = self._maybe_remat(layer_fn, xp, xs, lp, le)
+            xp, xs = hk.post_forward(f"joint.{l}", xp, xs)
+        hk.pre_forward("head")  # final adaRMS norm, action_out_proj (and the estimator's value head): never released early
         modf = ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
         out, _ = ops.adarms(xs, modf, Hs, ex.norm.eps)
         return out
@@ -411,6 +433,27 @@ class PI0Pytorch(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._engine = None
         return super().load_state_dict(*args, **kwargs)
+
+    # ---- sharded training (kai0_amd.sharded / kai0_amd.train) ---------------------------------------------------
+    def sharding_units(self):
+        """[(unit name, [parameters])] in forward-use order: what is gathered, used and released together.  The names are
+        the ones the forward announces through `unit_hooks.pre_forward / post_forward`."""
+        pe = self.paligemma_with_expert
+        vt = pe.paligemma.model.vision_tower.vision_model
+        lm, ex = pe.paligemma.model.language_model, pe.gemma_expert.model
+        units = [("siglip.embed", list(vt.embeddings.parameters()))]
+        units += [(f"siglip.{l}", list(layer.parameters())) for l, layer in enumerate(vt.encoder.layers)]
+        units.append(("prefix", [*vt.post_layernorm.parameters(), *pe.paligemma.model.multi_modal_projector.parameters(),
+                                 lm.embed_tokens.weight, *self.action_in_proj.parameters(), *self.time_mlp_in.parameters(),
+                                 *self.time_mlp_out.parameters()]))  # fmt: skip
+        units += [(f"joint.{l}", [*lp.parameters(), *le.parameters()]) for l, (lp, le) in enumerate(zip(lm.layers, ex.layers))]
+        taken = {id(p) for _, ps in units for p in ps}
+        dead = pe.gemma_expert.lm_head.weight
+        units.append(("head", [p for p in self.parameters() if id(p) not in taken and p is not dead]))
+        return units
+
+    def set_unit_hooks(self, hooks):
+        self.paligemma_with_expert.unit_hooks = hooks if hooks is not None else _NoUnitHooks()
 
     def gradient_checkpointing_enable(self):
         """pi0_pytorch.py:126-133. Activations fit in 288 GB HBM, so this is optional here; when enabled each
@@ -493,6 +536,7 @@ class PI0Pytorch(nn.Module):
             x_t = x_t.to(F32).contiguous()
         prefix, ppad, patt = self.embed_prefix(images, img_masks, lang_tokens, lang_masks)
         suffix, spad, satt, cond = self.embed_suffix(state, x_t, time)
+        prefix, suffix, cond = self.paligemma_with_expert.unit_hooks.post_forward("prefix", prefix, suffix, cond)
         B, P, Dp = prefix.shape
         Hs, De = suffix.shape[1], suffix.shape[2]
         qcode, kcode, pos = build_mask_codes(torch.cat([ppad, spad], dim=1), torch.cat([patt, satt], dim=1))
@@ -525,6 +569,9 @@ class PI0Pytorch(nn.Module):
         if noise is None:
             noise = self.sample_noise((bsize, self.config.action_horizon, self.config.action_dim), device)
         images, img_masks, lang_tokens, lang_masks, state = self._preprocess_observation(observation, train=False)
+        wait = getattr(self.paligemma_with_expert.unit_hooks, "wait_params", None)
+        if wait is not None:  # a sharded trainer owns the parameters: its in-flight all-gathers must have landed
+            wait()
         if self._engine is None or not self._engine.compatible(bsize, lang_tokens.shape[1], len(images)):
             self._engine = InferenceEngine(self, bsize, lang_tokens.shape[1], len(images))
         return self._engine.sample_actions(images, img_masks, lang_tokens, lang_masks, noise.to(F32), num_steps)

@@ -97,3 +97,43 @@ def create_policy(model, *, norm_stats: Mapping | None, tokenizer, action_dim: i
                     _transforms.PadStatesAndActions(action_dim)],
         output_transforms=[_transforms.Unnormalize(norm_stats, use_quantiles=use_quantile_norm), *robot_outputs, *repack.outputs],
         sample_kwargs=sample_kwargs, metadata=metadata, pytorch_device=pytorch_device)  # fmt: skip
+
+
+def create_trained_policy(train_config, checkpoint_dir, *, repack_transforms: _transforms.Group | None = None,
+                          sample_kwargs: dict[str, Any] | None = None, default_prompt: str | None = None,
+                          norm_stats: Mapping | None = None, pytorch_device: str | None = None) -> Policy:  # fmt: skip
+    """`policy_config.create_trained_policy` (policy_config.py:16-94) for torch checkpoints: `model.safetensors` in
+    `checkpoint_dir` -> `train_config.model.load_pytorch` -> bf16 storage -> the transform stack of the reference:
+      inputs : repack -> InjectDefaultPrompt -> data transforms -> Normalize -> model transforms
+      outputs: model outputs -> Unnormalize -> data outputs -> repack outputs
+    Norm stats come from `<checkpoint_dir>/assets/<asset_id>` (the stats the run was trained with) unless given.  A
+    checkpoint directory without `model.safetensors` is a JAX checkpoint: convert it first (kai0_amd.convert)."""
+    import os
+    import pathlib
+
+    from . import normalize as _normalize
+
+    repack_transforms = repack_transforms or _transforms.Group()
+    checkpoint_dir = pathlib.Path(checkpoint_dir)
+    weight_path = os.path.join(checkpoint_dir, "model.safetensors")
+    if not os.path.exists(weight_path):
+        raise FileNotFoundError(f"{weight_path} not found: kai0_amd serves torch checkpoints (model.safetensors); a JAX `params` "
+                                "checkpoint has to go through kai0_amd.convert first")  # fmt: skip
+    model = train_config.model.load_pytorch(train_config, weight_path)
+    model.paligemma_with_expert.to_bfloat16_for_selected_params("bfloat16")
+    data_config = train_config.data.create(train_config.assets_dirs, train_config.model)
+    if norm_stats is None:
+        if data_config.asset_id is None:
+            raise ValueError("Asset id is required to load norm stats.")
+        norm_stats = _normalize.load(checkpoint_dir / "assets" / data_config.asset_id)  # checkpoints.load_norm_stats
+    if pytorch_device is None:
+        pytorch_device = "cuda" if torch.cuda.is_available() else "cpu"
+    return Policy(
+        model,
+        transforms=[*repack_transforms.inputs, _transforms.InjectDefaultPrompt(default_prompt), *data_config.data_transforms.inputs,
+                    _transforms.Normalize(norm_stats, use_quantiles=data_config.use_quantile_norm),
+                    *data_config.model_transforms.inputs],
+        output_transforms=[*data_config.model_transforms.outputs,
+                           _transforms.Unnormalize(norm_stats, use_quantiles=data_config.use_quantile_norm),
+                           *data_config.data_transforms.outputs, *repack_transforms.outputs],
+        sample_kwargs=sample_kwargs, metadata=train_config.policy_metadata, is_pytorch=True, pytorch_device=pytorch_device)  # fmt: skip

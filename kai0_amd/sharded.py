@@ -1,30 +1,34 @@
-"""Sharded data-parallel engine: gradients reduce-scattered, optimizer state (f32 master + Adam moments) and the
-parameter update sharded 1/N per GPU, updated bf16 parameters all-gathered — RCCL over xGMI, overlapped with
-backward.
+"""Sharded data-parallel engine over RCCL / xGMI: one process per GPU, gradients reduce-scattered as backward produces them,
+optimizer state (f32 master + Adam moments) and the parameter update sharded 1/N per GPU, bf16 parameters all-gathered.
 
 What it replaces: DistributedDataParallel's bucketed all-reduce in the reference's PyTorch trainer
 (train_pytorch.py:440-447) and the GSPMD FSDP sharding of the JAX trainer (training/sharding.py:48-102).
 
-MI355X-first design:
-  * 288 GB of HBM per GPU: the bf16 model copy (7.2 GB) stays fully resident on every GPU, so forward/backward
-    never wait on a parameter gather (no all-gather in the critical path of a layer, no re-gather for backward);
-    what is sharded is what is big: 12 B/param of f32 master + moments and the gradient reduction.
-  * per step and GPU: one reduce-scatter (grads) + one all-gather (updated params) of the flat buffers,
-    = 2 x 7/8 x 7.2 GB over xGMI instead of DDP's all-reduce (same bytes) plus a replicated 16 B/param optimizer
-    pass; FSDP's third collective (backward re-gather) is not needed at all.
-  * few, large collectives: parameters are packed (reverse registration order = gradient-ready order) into flat
-    buckets of ~512 MB; a bucket's reduce-scatter is issued from the autograd hook of its last gradient, on RCCL's
-    stream, while backward keeps computing earlier layers.
-  * the whole optimizer is 3 kernels per bucket on flat shards (sum-of-squares, clip coefficient kept on device,
-    fused AdamW) — no per-tensor launches, no host sync.
+Two modes over the same buckets, collectives and kernels:
 
-The arithmetic is pluggable (`ShardOps`) only so the collective/partition logic can be exercised on CPU with the
-gloo backend in tests; the product default is the HIP kernels and it raises without them.
+  * "zero2" (default) — 288 GB of HBM per GPU: the bf16 model copy (7.2 GB) stays resident on every GPU, so no layer ever
+    waits on a gather inside forward / backward and nothing is re-gathered for backward.  Per step and GPU: one
+    reduce-scatter of the gradients + one all-gather of the updated parameters = 2 x (N-1)/N x 7.2 GB over xGMI.  The
+    all-gathers are issued per bucket, in forward-use order, right after each bucket's AdamW, and are NOT waited for in
+    step(): the next forward waits per unit (`pre_forward`), so the gather of layer k+1.. hides behind the compute of
+    layers ..k.
+  * "fsdp" — parameters sharded too (training/sharding.py:48-102; north_star "optimizer/grad/param FSDP-style"): the
+    persistent bf16 copy is the 1/N shard; a bucket's full parameters exist only around its use — gathered one bucket
+    ahead of the forward, freed after it, gathered again one bucket ahead of the backward, freed when the bucket's
+    gradients have been reduce-scattered.  3 x (N-1)/N x 7.2 GB per step; saves (N-1)/N x 7.2 GB of HBM.
+
+Unit = what the model uses together (one SigLIP layer; one joint Gemma-2B + expert layer; the embeddings; the heads): the
+model reports them in forward-use order (`sharding_units()`), consecutive units are packed into buckets of ~512 MB, a
+bucket's reduce-scatter is issued from inside backward the moment its last gradient has been written (the backward shims
+write straight into the flat gradient buffer: no copy, no autograd accumulation).  SUM collectives only (the loss is
+scaled by 1/N), so the gloo tests on CPU drive exactly the call path RCCL runs.
+
+The whole optimizer is 3 kernels per bucket on flat shards (sum of squares, clip coefficient kept on device, fused
+AdamW) — no per-tensor launches, no host sync.  The arithmetic is pluggable (`ShardOps`) only so the collective /
+partition logic can be exercised on CPU with gloo; the product default is the HIP kernels and raises without them.
 """
 
 from __future__ import annotations
-
-import math
 
 import functools
 import os
@@ -55,9 +59,10 @@ class HipShardOps:
 
 
 class _Bucket:
-    def __init__(self, params, dtype, world, rank, device, align=256, alias_shard=True):
-        self.params = params
-        self.dtype = dtype
+    """Flat buffers of the same-dtype parameters of a run of consecutive units."""
+
+    def __init__(self, params, names, dtype, world, rank, device, *, alias_shard: bool, fsdp: bool, align=256):
+        self.params, self.names, self.dtype = params, names, dtype
         self.offsets = []
         off = 0
         for p in params:
@@ -66,93 +71,235 @@ class _Bucket:
         unit = world * align
         self.numel = (off + unit - 1) // unit * unit
         self.shard = self.numel // world
+        self.lo = rank * self.shard
         self.flat_param = torch.zeros(self.numel, dtype=dtype, device=device)
         self.flat_grad = torch.zeros(self.numel, dtype=dtype, device=device)
         for p, o in zip(params, self.offsets):
             self.flat_param[o : o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o : o + p.numel()].view(p.shape)
-        lo = rank * self.shard
-        self.param_shard = self.flat_param[lo : lo + self.shard]
-        # one GPU: the "shard" is the whole buffer — alias it instead of copying
-        self.grad_shard = self.flat_grad if (world == 1 and alias_shard) else torch.zeros(self.shard, dtype=dtype, device=device)
-        for p, o in zip(params, self.offsets):
-            # producers that can write a gradient in place (LinearFn wgrad, EmbedFn) pick this up
+            # producers that can write a gradient in place (LinearFn wgrad, EmbedFn, ...) pick this up
             p._kai0_grad_out = self.flat_grad[o : o + p.numel()].view(p.shape)
-        self.master = self.param_shard.to(F32).clone()
-        self.exp_avg = torch.zeros(self.shard, dtype=F32, device=device)
-        self.exp_avg_sq = torch.zeros(self.shard, dtype=F32, device=device)
+        self.fsdp = fsdp
+        self.full_nbytes = self.flat_param.untyped_storage().nbytes()
+        self.resident = True  # fsdp: whether flat_param's storage currently exists
+        self.param_shard = None  # set by carve_shards() (after the construction-time broadcast)
+        # one GPU: the "shard" is the whole buffer — alias it instead of copying
+        self.grad_shard = self.flat_grad if alias_shard else torch.zeros(self.shard, dtype=dtype, device=device)
+        self.master = self.exp_avg = self.exp_avg_sq = None
         self.pending = len(params)
         self.arrived = set()
         self.stale = set()  # parameters whose slice of flat_grad still holds the previous step's gradient
-        self.work = None
+        self.rs_work = None  # in-flight reduce-scatter of the gradients
+        self.ag_work = None  # in-flight all-gather of the parameters
+
+    def carve_shards(self):
+        sl = self.flat_param[self.lo : self.lo + self.shard]
+        # fsdp: the shard outlives the full buffer, so it owns its memory; zero2: a slice (in-place all-gather)
+        self.param_shard = sl.clone() if self.fsdp else sl
+        self.master = sl.to(F32).clone()
+        self.exp_avg = torch.zeros(self.shard, dtype=F32, device=sl.device)
+        self.exp_avg_sq = torch.zeros(self.shard, dtype=F32, device=sl.device)
+
+
+class _BackwardMark(torch.autograd.Function):
+    """Identity on a unit's outputs whose backward tells the engine that the unit's backward is about to start
+    (fsdp: its parameters are gathered again, the bucket before it is prefetched)."""
+
+    @staticmethod
+    def forward(ctx, engine, unit, *tensors):
+        ctx.engine, ctx.unit = engine, unit
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.engine._pre_backward(ctx.unit)
+        return (None, None, *grads)
 
 
 class ShardedDataParallel:
     def __init__(self, params, *, world_size: int, rank: int, group=None, ops=None, betas=(0.9, 0.95), eps=1e-8,
-                 weight_decay=1e-10, max_grad_norm=1.0, bucket_bytes: int = 512 << 20):  # fmt: skip
+                 weight_decay=1e-10, max_grad_norm=1.0, bucket_bytes: int = 512 << 20, units=None, mode: str = "zero2",
+                 prefetch: int = 1, sync_params: bool = True):  # fmt: skip
+        """`params`: parameters, or (name, parameter) pairs (names make the checkpoint world-size independent).
+        `units`: [(unit name, [parameters])] in forward-use order; parameters not listed form a last unit "rest"."""
+        if mode not in ("zero2", "fsdp"):
+            raise ValueError(f"mode must be 'zero2' or 'fsdp', got {mode!r}")
         self.world, self.rank, self.group = world_size, rank, group
         self.ops = ops or HipShardOps()
         self.betas, self.eps, self.wd, self.max_grad_norm = betas, eps, weight_decay, max_grad_norm
+        self.prefetch = max(0, int(prefetch))
         self.step_count = 0
-        seen, uniq = set(), []
-        for p in params:
+        seen, uniq, names = set(), [], {}
+        for i, item in enumerate(params):
+            name, p = item if isinstance(item, tuple) else (f"param.{i}", item)
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 uniq.append(p)
+                names[id(p)] = name
         if not uniq:
             raise ValueError("no trainable parameters")
-        self.device = uniq[0].device
-        # KAI0_FORCE_COLLECTIVES=1: run the reduce-scatter / all-gather calls even with one rank (validates the RCCL call
-        # pattern on a single-GPU box; tools/nccl_same_gpu_probe.py)
-        self.collectives = world_size > 1 or (os.environ.get("KAI0_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
-        self.backend = dist.get_backend(group) if self.collectives else "none"
-        # gradients become ready in (roughly) reverse registration order: pack buckets in that order
-        self.buckets: list[_Bucket] = []
-        for dtype in (BF16, F32):
-            cur, cur_bytes = [], 0
-            for p in reversed([q for q in uniq if q.dtype == dtype]):
-                cur.append(p)
-                cur_bytes += p.numel() * p.element_size()
-                if cur_bytes >= bucket_bytes:
-                    self.buckets.append(_Bucket(cur, dtype, world_size, rank, self.device, alias_shard=not self.collectives))
-                    cur, cur_bytes = [], 0
-            if cur:
-                self.buckets.append(_Bucket(cur, dtype, world_size, rank, self.device, alias_shard=not self.collectives))
         other = [p for p in uniq if p.dtype not in (BF16, F32)]
         if other:
             raise TypeError(f"unsupported parameter dtype {other[0].dtype}")
+        self.device = uniq[0].device
+        # KAI0_FORCE_COLLECTIVES=1: run the collectives even with one rank (validates the RCCL call pattern on a one-GPU box)
+        self.collectives = world_size > 1 or (os.environ.get("KAI0_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+        self.mode = mode if self.collectives else "zero2"  # without peers there is nothing to shard
+        fsdp = self.mode == "fsdp"
+
+        # ---- units -> buckets (forward-use order; a unit is never split) ----------------------------------------
+        ulist, assigned = [], set()
+        for uname, ups in units or []:
+            ps = [p for p in ups if id(p) in seen and id(p) not in assigned]
+            assigned.update(id(p) for p in ps)
+            if ps:
+                ulist.append((uname, ps))
+        rest = [p for p in uniq if id(p) not in assigned]
+        if rest:
+            if units:
+                ulist.append(("rest", rest))
+            else:  # no unit information: every parameter its own unit, registration order
+                ulist += [(names[id(p)], [p]) for p in rest]
+        self.buckets: list[_Bucket] = []
+        self.groups: list[list[int]] = []  # group g -> bucket indices (one per dtype present)
+        self.unit_group: dict[str, int] = {}
+        self._group_last_unit: list[str] = []
+        cur, cur_bytes, cur_units = [], 0, []
+
+        def close():
+            nonlocal cur, cur_bytes, cur_units
+            if not cur:
+                return
+            g = len(self.groups)
+            ids = []
+            for dtype in (BF16, F32):
+                ps = [p for p in cur if p.dtype == dtype]
+                if ps:
+                    ids.append(len(self.buckets))
+                    self.buckets.append(_Bucket(ps, [names[id(p)] for p in ps], dtype, world_size, rank, self.device,
+                                                alias_shard=not self.collectives, fsdp=fsdp))  # fmt: skip
+            self.groups.append(ids)
+            for u in cur_units:
+                self.unit_group[u] = g
+            self._group_last_unit.append(cur_units[-1])
+            cur, cur_bytes, cur_units = [], 0, []
+
+        for uname, ps in ulist:
+            cur += ps
+            cur_units.append(uname)
+            cur_bytes += sum(p.numel() * p.element_size() for p in ps)
+            if cur_bytes >= bucket_bytes:
+                close()
+        close()
+
         self._where = {}
-        for b in self.buckets:
+        for bi, b in enumerate(self.buckets):
             for p, o in zip(b.params, b.offsets):
                 self._where[p] = (b, o)
                 p.register_post_accumulate_grad_hook(self._on_grad)
                 p._kai0_grad_done = functools.partial(self._on_grad_inplace, p)
+        self._bucket_group = {}
+        for g, ids in enumerate(self.groups):
+            for bi in ids:
+                self._bucket_group[id(self.buckets[bi])] = g
+
+        # replicas must start identical (DDP broadcasts rank 0's module at construction): a rank that initialised or loaded
+        # different weights would otherwise contribute its own slice to the first all-gather, silently
+        if self.collectives and sync_params:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            for b in self.buckets:
+                dist.broadcast(b.flat_param, src=src, group=group)
+        for b in self.buckets:
+            b.carve_shards()
         self._sumsq = torch.zeros(1, dtype=F32, device=self.device)
         self._coef = torch.ones(1, dtype=F32, device=self.device)
         self._norm = torch.zeros(1, dtype=F32, device=self.device)
+        self._in_backward = False
+        if fsdp:
+            for g in range(len(self.groups)):
+                self._release(g)
 
     # ------------------------------------------------------------------------------------------ collectives
-    def _reduce_scatter_avg(self, b: _Bucket):
+    def _reduce_scatter(self, b: _Bucket):
+        """SUM of the ranks' gradients (the loss carries the 1/N), each rank keeping its 1/N slice."""
         if not self.collectives:
             return None  # grad_shard aliases flat_grad
-        if self.backend == "nccl":  # RCCL
-            return dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        # gloo (CPU tests): no reduce_scatter / AVG — all-reduce then keep the local shard
-        dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        lo = self.rank * b.shard
-        b.grad_shard.copy_(b.flat_grad[lo : lo + b.shard] / self.world)
-        return None
+        return dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _all_gather(self, b: _Bucket):
         if not self.collectives:
             return None
-        if self.backend == "nccl":
-            return dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True)
-        chunks = [torch.empty_like(b.param_shard) for _ in range(self.world)]
-        dist.all_gather(chunks, b.param_shard.clone(), group=self.group)
-        for r, c in enumerate(chunks):
-            b.flat_param[r * b.shard : (r + 1) * b.shard].copy_(c)
-        return None
+        return dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True)
+
+    # ---- parameter residency (fsdp) / gather hand-off (zero2) ---------------------------------------------
+    def _issue_gather(self, g: int):
+        if g < 0 or g >= len(self.groups):
+            return
+        for bi in self.groups[g]:
+            b = self.buckets[bi]
+            if b.fsdp and not b.resident:
+                b.flat_param.untyped_storage().resize_(b.full_nbytes)
+                b.resident = True
+                b.ag_work = self._all_gather(b)
+
+    def _ensure(self, g: int):
+        """The parameters of group g are complete on this GPU (for every kernel enqueued on the current stream from now on)."""
+        self._issue_gather(g)
+        for bi in self.groups[g]:
+            b = self.buckets[bi]
+            if b.ag_work is not None:
+                b.ag_work.wait()
+                b.ag_work = None
+
+    def _release(self, g: int):
+        for bi in self.groups[g]:
+            b = self.buckets[bi]
+            if b.fsdp and b.resident:
+                if b.ag_work is not None:
+                    b.ag_work.wait()
+                    b.ag_work = None
+                b.flat_param.untyped_storage().resize_(0)
+                b.resident = False
+
+    # ---- unit hooks: called by the model around every unit's compute ------------------------------------------
+    def pre_forward(self, unit: str):
+        g = self.unit_group.get(unit)
+        if g is None:
+            return
+        self._ensure(g)
+        if self.mode == "fsdp" and not self._in_backward:
+            for k in range(1, self.prefetch + 1):
+                self._issue_gather(g + k)
+
+    def post_forward(self, unit: str, *tensors):
+        """Marks the end of a unit's forward; returns `tensors` (wrapped so that the unit's backward announces itself)."""
+        g = self.unit_group.get(unit)
+        if g is None or self.mode != "fsdp":
+            return tensors
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            tensors = _BackwardMark.apply(self, unit, *tensors)
+        if not self._in_backward and self._group_last_unit[g] == unit and g != len(self.groups) - 1:
+            self._release(g)  # (the last group is used again at once by the backward: it stays)
+        return tensors
+
+    def _pre_backward(self, unit: str):
+        self._in_backward = True
+        g = self.unit_group[unit]
+        self._ensure(g)
+        for k in range(1, self.prefetch + 1):
+            self._issue_gather(g - k)
+
+    def wait_params(self):
+        """Every parameter complete on this GPU (callers without unit hooks: plain modules, checkpointing, inference)."""
+        for g in range(len(self.groups)):
+            self._ensure(g)
+
+    materialize = wait_params
+
+    def release_params(self):
+        """fsdp: drop the full parameter buffers again (after `materialize()` for a checkpoint / an inference call)."""
+        for g in range(len(self.groups)):
+            self._release(g)
 
     # ------------------------------------------------------------------------------------------------ hooks
     def _on_grad(self, p):
@@ -174,28 +321,64 @@ class ShardedDataParallel:
         if id(p) in b.arrived:
             raise RuntimeError("a parameter received two gradients in one step: the in-place gradient path supports "
                                "one use per parameter per backward")  # fmt: skip
+        self._in_backward = True
         b.arrived.add(id(p))
         b.pending -= 1
         if b.pending == 0:
-            b.work = self._reduce_scatter_avg(b)  # overlaps with the rest of backward
+            b.rs_work = self._reduce_scatter(b)  # overlaps with the rest of backward
+            if b.fsdp:
+                g = self._bucket_group[id(b)]
+                if all(self.buckets[bi].pending == 0 for bi in self.groups[g]):
+                    self._release(g)  # nothing in backward reads these parameters any more
+
+    def _check_views(self):
+        """Every parameter must still be the view into its flat buffer that the optimizer updates."""
+        for b in self.buckets:
+            if not b.resident:
+                continue
+            base, es = b.flat_param.data_ptr(), b.flat_param.element_size()
+            for p, o, n in zip(b.params, b.offsets, b.names):
+                if p.data_ptr() != base + o * es or p.dtype != b.dtype:
+                    raise RuntimeError(
+                        f"parameter {n} no longer aliases the trainer's flat buffer (its .data was rebound: dtype cast, "
+                        ".to(device), to_bfloat16_for_selected_params, ...): the optimizer would update memory the model does "
+                        "not read.  Load / cast weights BEFORE constructing the Trainer, or write them in place "
+                        "(p.data.copy_ / load_state_dict) and call sync_master_from_params().")  # fmt: skip
+
+    @torch.no_grad()
+    def sync_master_from_params(self):
+        """Adopt weights written into the model after construction (load_state_dict, p.data.copy_, model_arithmetic): the
+        f32 master copies (and the fsdp shards) are re-read from the parameters; Adam moments are kept.  Collective in fsdp
+        mode only in the sense that every rank must call it."""
+        self.wait_params()
+        self._check_views()
+        for b in self.buckets:
+            sl = b.flat_param[b.lo : b.lo + b.shard]
+            b.master.copy_(sl)
+            if b.fsdp:
+                b.param_shard.copy_(sl)
+        if self.mode == "fsdp":
+            self.release_params()
 
     # ------------------------------------------------------------------------------------------------- step
     @torch.no_grad()
     def step(self, lr: float):
-        """Finish the gradient reduction, clip by the global norm, update the local shards, gather the parameters.
-        Returns the global (pre-clip) gradient norm as a 1-element device tensor."""
+        """Finish the gradient reduction, clip by the global norm, update the local shards, start the parameter all-gathers
+        (zero2; waited for by the next forward, unit by unit).  Returns the global (pre-clip) gradient norm as a 1-element
+        device tensor."""
         self.step_count += 1
+        self._check_views()
         for b in self.buckets:
             if b.pending > 0:  # parameters that received no gradient this step contribute zeros
                 for p, o in zip(b.params, b.offsets):
                     if id(p) in b.stale and id(p) not in b.arrived:  # ... not what an earlier step left in their slice
                         b.flat_grad[o : o + p.numel()].zero_()
                         b.stale.discard(id(p))
-                b.work = self._reduce_scatter_avg(b)
+                b.rs_work = self._reduce_scatter(b)
         for b in self.buckets:
-            if b.work is not None:
-                b.work.wait()
-                b.work = None
+            if b.rs_work is not None:
+                b.rs_work.wait()
+                b.rs_work = None
         coef = None
         if self.max_grad_norm is not None:
             self._sumsq.zero_()
@@ -205,14 +388,11 @@ class ShardedDataParallel:
                 dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.group)
             self.ops.clip_coef(self._sumsq, self.max_grad_norm, self._coef, self._norm)
             coef = self._coef
-        works = []
-        for b in self.buckets:
+        for b in self.buckets:  # forward-use order: the first layers' parameters are complete first
             self.ops.adamw(b.master, b.exp_avg, b.exp_avg_sq, b.grad_shard, b.param_shard, lr=lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self.step_count, clip_coef=coef)  # fmt: skip
-            works.append(self._all_gather(b))
-        for w in works:
-            if w is not None:
-                w.wait()
+            if not b.fsdp:
+                b.ag_work = self._all_gather(b)  # not waited for here: pre_forward / wait_params do
         # Every gradient producer overwrites its parameter's whole slice, so the 7 GB of flat gradients are NOT cleared per
         # step: a slice is zeroed only if its producer accumulates into it (the embedding scatter: `_kai0_grad_accumulates`)
         # or, lazily in the next step(), if it holds an old gradient and no new one arrived.
@@ -230,25 +410,85 @@ class ShardedDataParallel:
                         b.stale.add(id(p))
             b.pending = len(b.params)
             b.arrived.clear()
+        self._in_backward = False
+        if self.mode == "fsdp":
+            self.release_params()
+            self._issue_gather(0)  # the next forward starts with group 0
         return self._norm
 
     # ------------------------------------------------------------------------------------------ checkpointing
-    def state_dict(self):
-        return {
-            "step": self.step_count,
-            "shards": [{"master": b.master, "exp_avg": b.exp_avg, "exp_avg_sq": b.exp_avg_sq} for b in self.buckets],
-            "world": self.world,
-            "rank": self.rank,
-        }
+    @torch.no_grad()
+    def state_dict(self, param_order=None):
+        """World-size independent optimizer state, shaped like `torch.optim.AdamW.state_dict()` (the reference's
+        `optimizer.pt`, train_pytorch.py:170-180): state[i] = {step, exp_avg, exp_avg_sq} for parameter i of `param_order`
+        (names in `model.named_parameters()` order — the order torch indexes them in; default: this engine's bucket order),
+        plus this engine's f32 `master` copy and the name list.  Parameters the engine does not train have no entry, as in
+        torch.  COLLECTIVE: every rank calls it; rank 0 gets the dictionary (CPU tensors), the others None."""
+        by_name = {}
+        for b in self.buckets:
+            fulls = {}
+            for key in ("master", "exp_avg", "exp_avg_sq"):
+                sh = getattr(b, key)
+                if self.collectives:
+                    full = torch.empty(b.numel, dtype=F32, device=self.device)
+                    dist.all_gather_into_tensor(full, sh, group=self.group)
+                else:
+                    full = sh
+                fulls[key] = full
+            if self.rank == 0:
+                for p, o, n in zip(b.params, b.offsets, b.names):
+                    by_name[n] = {"step": torch.tensor(float(self.step_count)),
+                                  **{k: v[o : o + p.numel()].view(p.shape).cpu().clone() for k, v in fulls.items()}}  # fmt: skip
+            del fulls
+        if self.rank != 0:
+            return None
+        order = list(param_order) if param_order is not None else [n for b in self.buckets for n in b.names]
+        missing = set(by_name) - set(order)
+        if missing:
+            raise KeyError(f"param_order lacks trained parameters: {sorted(missing)[:3]} ...")
+        return {"state": {i: by_name[n] for i, n in enumerate(order) if n in by_name},
+                "param_groups": [{"betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "params": list(range(len(order)))}],
+                "param_names": order, "step": self.step_count}  # fmt: skip
 
-    def load_state_dict(self, sd):
-        if sd["world"] != self.world or sd["rank"] != self.rank:
-            raise ValueError("sharded optimizer state was saved with a different world size / rank")
-        self.step_count = sd["step"]
-        for b, s in zip(self.buckets, sd["shards"], strict=True):
-            b.master.copy_(s["master"])
-            b.exp_avg.copy_(s["exp_avg"])
-            b.exp_avg_sq.copy_(s["exp_avg_sq"])
+    @torch.no_grad()
+    def load_state_dict(self, sd, param_order=None):
+        """Every rank loads the same dictionary and keeps its slices — any world size, any bucket layout.  Entries are matched
+        by parameter name (`param_names` in the file, else `param_order`); a plain torch AdamW state dict (the reference's
+        optimizer.pt: index = position in model.parameters(), bf16 moments, no master) therefore loads too: moments are
+        widened to f32 and the master copies are taken from the current parameters.  The model weights must already be in
+        place (load them first): the fsdp shards are re-read from them."""
+        pnames = sd.get("param_names", param_order)
+        if pnames is None:
+            raise ValueError("optimizer state without `param_names` needs param_order (names in model.named_parameters() order)")
+        state = sd["state"]
+        by_name = {pnames[i]: ent for i, ent in state.items()}
+        steps = [float(s["step"]) for s in state.values() if "step" in s]
+        self.step_count = int(sd.get("step", max(steps) if steps else 0))
+        need_master = False
+        for b in self.buckets:
+            for p, o, n in zip(b.params, b.offsets, b.names):
+                ent = by_name.get(n)
+                if ent is None:
+                    raise KeyError(f"optimizer state has no entry for parameter {n}")
+                lo, hi = max(o, b.lo), min(o + p.numel(), b.lo + b.shard)
+                for key in ("exp_avg", "exp_avg_sq", "master"):
+                    if key not in ent:
+                        need_master = True
+                        continue
+                    if ent[key].numel() != p.numel():
+                        raise ValueError(f"optimizer state of {n}: {tuple(ent[key].shape)} vs parameter {tuple(p.shape)}")
+                    if lo < hi:
+                        getattr(b, key)[lo - b.lo : hi - b.lo].copy_(ent[key].reshape(-1)[lo - o : hi - o].to(F32))
+        self.wait_params()
+        self._check_views()
+        for b in self.buckets:
+            sl = b.flat_param[b.lo : b.lo + b.shard]
+            if need_master:  # no master copies in the file: adopt the current parameters
+                b.master.copy_(sl)
+            if b.fsdp:
+                b.param_shard.copy_(sl)
+        if self.mode == "fsdp":
+            self.release_params()
 
     def optimizer_state_bytes(self) -> int:
         return sum(3 * 4 * b.shard for b in self.buckets)

@@ -75,8 +75,8 @@ def test_backward_matches_oracle_autograd(pair):
         r = rel(gm[n], g)
         table.append((r, n, float(g.norm())))
         checked += 1
-        # embedding rows touched by few tokens and tiny bias grads are noisier in bf16
-        tol = 0.08 if ("embed_tokens" in n or n.endswith("bias") or "position_embedding" in n) else 0.05
+        # ~2x the worst rel-L2 measured on MI355X (1.2e-2, gpurun_out/grad_table.txt; bf16 oracle vs fp32 oracle is the same)
+        tol = 0.025
         if r >= tol:
             bad.append((r, n))
     table.sort(reverse=True)
@@ -340,3 +340,88 @@ def test_data_loader_device_feed_drives_the_trainer():
     assert len(seen) == 3
     for i, a in enumerate(seen):
         assert torch.equal(a, torch.as_tensor(np.stack([ds[4 * i + j]["actions"] for j in range(4)])))
+
+
+def test_policy_infer_over_the_hip_model(tmp_path):
+    """The serve path end to end on the GPU (policy.py:67-122): `create_trained_policy(train_config, checkpoint_dir)` ->
+    raw Agilex observation -> transform stack -> H2D -> `sample_actions` (hipGraph) -> D2H -> unnormalise -> robot actions,
+    against the CPU oracle fed with the same transformed observation and noise."""
+    import numpy as np
+    from test_training_config_cpu import G, _agilex_cfg, _checkpoint
+
+    from kai0_amd import policy as _policy
+    from kai0_amd.preprocessing import Observation, preprocess_observation
+    from oracle.pi0_oracle import OraclePI0, SimpleObs
+    from tiny import tiny_cfgs
+
+    cfg = _agilex_cfg(use_delta_joint_actions=False)
+    model, ck, stats = _checkpoint(tmp_path, cfg, seed=9)
+    pol = _policy.create_trained_policy(cfg, ck, sample_kwargs={"num_steps": 10}, pytorch_device="cuda:0")
+    rng = np.random.default_rng(1)
+    cams = {k: rng.integers(0, 256, size=(3, 48, 64), dtype=np.uint8) for k in ("top_head", "hand_left", "hand_right")}
+    state = rng.uniform(-1.0, 1.0, size=14)
+    noise = rng.normal(size=(10, 32)).astype(np.float32)
+    raw = {"images": cams, "state": state, "prompt": "fold the cloth"}
+    import time as _time
+
+    res = pol.infer(dict(raw), noise=noise)
+    t0 = _time.perf_counter()
+    res = pol.infer(dict(raw), noise=noise)
+    wall_ms = (_time.perf_counter() - t0) * 1e3
+    assert res["actions"].shape == (10, 14) and res["actions"].dtype in (np.float32, np.float64)
+    print(f"Policy.infer (tiny model): wall {wall_ms:.2f} ms, model {res['policy_timing']['infer_ms']:.2f} ms")
+    # the oracle on the same transformed inputs
+    _, ocfg = tiny_cfgs(max_token_len=64)
+    oracle = OraclePI0(ocfg)
+    oracle.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
+    inp = pol._input_transform(dict(raw))
+    batched = {k: ({kk: torch.from_numpy(np.asarray(vv))[None] for kk, vv in v.items()} if isinstance(v, dict)
+                   else torch.from_numpy(np.asarray(v))[None]) for k, v in inp.items()}  # fmt: skip
+    obs = preprocess_observation(Observation.from_dict(batched), train=False, image_resolution=(56, 56))
+    sobs = SimpleObs(images=dict(obs.images), image_masks=dict(obs.image_masks), state=obs.state, tokenized_prompt=obs.tokenized_prompt,
+                     tokenized_prompt_mask=obs.tokenized_prompt_mask, token_ar_mask=None, token_loss_mask=None)  # fmt: skip
+    with torch.no_grad():
+        ref = oracle.sample_actions(sobs, torch.from_numpy(noise)[None], num_steps=10)
+    want = pol._output_transform({"state": inp["state"], "actions": ref[0].numpy()})["actions"]
+    err = np.abs(res["actions"] - want).max() / (np.abs(want).max() + 1e-9)
+    print(f"Policy.infer vs oracle: max rel err {err:.3e}")
+    assert err < 2e-2
+
+
+@pytest.mark.parametrize("mode", ["zero2", "fsdp"])
+def test_trainer_with_rccl_collectives_equals_collective_free_engine(pair, mode, monkeypatch):
+    """The RCCL call pattern of both sharding modes (SUM reduce-scatter issued from inside backward, all-gather awaited unit by
+    unit / just-in-time gather + release, async work handles) on the ONE GPU of the test box: RCCL refuses two ranks on one
+    device, so a 1-rank group runs the collectives as self-copies; results must equal the collective-free engine bit for
+    bit.  (world-2 logic: tests/test_sharded_cpu.py on gloo — the same code path.)"""
+    import torch.distributed as dist
+    from tiny import build_pair
+
+    from kai0_amd.train import Trainer
+
+    dev = pair["dev"]
+    args = (pair["gobs"], pair["actions"].to(dev))
+    kw = dict(noise=pair["noise"].to(dev), time=pair["time"].to(dev))
+
+    def run(collective):
+        model, _, _, _ = build_pair(dev, seed=3, std=0.08)
+        model.train()
+        tr = Trainer(model, world_size=1, rank=0, peak_lr=1e-3, warmup_steps=0, decay_steps=10, end_lr=1e-3, clip_norm=1.0,
+                     bucket_bytes=1 << 16, mode=mode)  # fmt: skip
+        assert tr.engine.collectives == collective and tr.engine.mode == (mode if collective else "zero2")
+        losses = [float(tr.train_step(*args, **kw)) for _ in range(3)]
+        tr.params_ready()
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in model.parameters()], float(tr.last_grad_norm)
+
+    base = run(False)
+    monkeypatch.setenv("KAI0_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29617")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        got = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert got[0] == base[0] and got[2] == base[2]
+    assert all(torch.equal(a, b) for a, b in zip(got[1], base[1]))

@@ -1,9 +1,12 @@
-"""world_size-2 gloo tests of the sharded data-parallel engine (collective / partition logic on CPU).
+"""world_size-2 gloo tests of the sharded data-parallel engine and the Trainer (collective / partition logic on CPU).
 
-The shard arithmetic is injected (`TorchShardOps`, a torch restatement of the HIP kernels' math — test-side
-oracle); the product default (`HipShardOps`) needs the GPU and is covered by tests/test_model_gpu.py."""
+gloo runs `reduce_scatter_tensor` / `all_gather_into_tensor` / `broadcast` on bf16 and f32, so these tests drive exactly the
+call path RCCL runs on the GPUs (SUM collectives, the 1/N in the loss).  The shard arithmetic is injected (`TorchShardOps`, a
+torch restatement of the HIP kernels' math — test-side oracle); the product default (`HipShardOps`) needs the GPU and is
+covered by tests/test_model_gpu.py."""
 
 import os
+import socket
 import tempfile
 
 import pytest
@@ -30,66 +33,256 @@ class TorchShardOps:
         param.copy_(master.to(param.dtype))
 
 
-def _toy_model():
-    torch.manual_seed(0)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn(fn, world=2, *args):
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(fn, args=(world, _free_port(), tmp, *args), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(tmp, f"ok{r}")) for r in range(world))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _done(rank, tmp):
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _toy_model(seed=0):
+    torch.manual_seed(seed)
     m = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.Tanh(), torch.nn.Linear(40, 8))
     m[0].weight.data = m[0].weight.data.to(torch.bfloat16).float()  # keep values bf16-representable
     return m
 
 
-def _worker(rank, world, port, tmp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+class UnitStack(torch.nn.Module):
+    """A stack of blocks that announces its sharding units the way PI0Pytorch does (pre_forward / post_forward)."""
+
+    def __init__(self, n=5, d=16, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.blocks = torch.nn.ModuleList([torch.nn.Linear(d, d) for _ in range(n)])
+        self.head = torch.nn.Linear(d, 4)
+        for i, b in enumerate(self.blocks):  # both dtypes in every unit, as in the real model (bf16 matrices, f32 norms)
+            if i % 2 == 0:
+                b.weight.data = b.weight.data.to(torch.bfloat16)
+                b.bias.data = b.bias.data.to(torch.bfloat16)
+        self.hooks = None
+
+    def sharding_units(self):
+        return [(f"block.{i}", list(b.parameters())) for i, b in enumerate(self.blocks)] + [("head", list(self.head.parameters()))]
+
+    def forward(self, x):
+        hk = self.hooks
+        for i, b in enumerate(self.blocks):
+            if hk:
+                hk.pre_forward(f"block.{i}")
+            x = torch.tanh(torch.nn.functional.linear(x.to(b.weight.dtype), b.weight, b.bias)).float()
+            if hk:
+                (x,) = hk.post_forward(f"block.{i}", x)
+        if hk:
+            hk.pre_forward("head")
+        return self.head(x)
+
+
+# ------------------------------------------------------------------------------------------------ zero2, plain modules
+def _worker_zero2(rank, world, port, tmp):
+    _init(rank, world, port)
     from kai0_amd.sharded import ShardedDataParallel
 
-    model = _toy_model()
-    ref = _toy_model()
-    eng = ShardedDataParallel(model.parameters(), world_size=world, rank=rank, ops=TorchShardOps(), weight_decay=1e-2,
-                              max_grad_norm=0.5, bucket_bytes=1024)
-    assert len(eng.buckets) > 1
+    model = _toy_model(seed=rank)  # DIFFERENT initial weights per rank: construction broadcasts rank 0's
+    ref = _toy_model(seed=0)
+    eng = ShardedDataParallel(list(model.named_parameters()), world_size=world, rank=rank, ops=TorchShardOps(), weight_decay=1e-2,
+                              max_grad_norm=0.5, bucket_bytes=1024)  # fmt: skip
+    assert len(eng.buckets) > 1 and eng.mode == "zero2"
+    for p, r in zip(model.parameters(), ref.parameters()):
+        assert torch.equal(p, r), "replicas must start from rank 0's weights"
     ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2)
     g = torch.Generator().manual_seed(1)
     data = torch.randn(3, world, 6, 24, generator=g)
     for step in range(3):
-        # each rank sees its slice; the reference sees the whole global batch
-        model(data[step, rank]).pow(2).mean().backward()
+        # each rank sees its slice (loss scaled by 1/world: gradients are SUMMED); the reference sees the global batch
+        eng.wait_params()
+        (model(data[step, rank]).pow(2).mean() / world).backward()
         norm = eng.step(1e-2)
         ref.zero_grad()
         ref(data[step].reshape(-1, 24)).pow(2).mean().backward()
         rn = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
         ropt.step()
         assert abs(float(norm) - float(rn)) < 1e-5 * max(1.0, float(rn)), (float(norm), float(rn))
+        eng.wait_params()
         for p, r in zip(model.parameters(), ref.parameters()):
             assert torch.allclose(p, r, atol=2e-6, rtol=1e-5), (step, (p - r).abs().max())
             assert p.grad is None
-    # every rank holds the same full parameters, and 1/world of the optimizer state
-    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-    gathered = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
-    assert all(torch.equal(gathered[0], t) for t in gathered)
     total = sum(p.numel() for p in model.parameters())
-    assert eng.optimizer_state_bytes() < 12 * total / world + 12 * 2 * 256 * world
-    sd = eng.state_dict()
+    assert eng.optimizer_state_bytes() < 12 * total / world + 12 * 4 * 256 * world
+    # world-size independent optimizer state: gathered on rank 0, reloaded everywhere, torch-shaped
+    sd = eng.state_dict([n for n, _ in model.named_parameters()])
+    box = [sd]
+    dist.broadcast_object_list(box, src=0)
+    sd = box[0]
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq", "master"} and sd["state"][0]["exp_avg"].shape == (40, 24)
+    for (n, p), (i, st) in zip(model.named_parameters(), sd["state"].items()):
+        assert sd["param_names"][i] == n and torch.allclose(st["master"], p.detach(), atol=1e-7)
+    before = [(b.master.clone(), b.exp_avg.clone(), b.exp_avg_sq.clone()) for b in eng.buckets]
+    for b in eng.buckets:
+        b.master.zero_(), b.exp_avg.zero_(), b.exp_avg_sq.zero_()
     eng.load_state_dict(sd)
-    if rank == 0:
-        open(os.path.join(tmp, "ok"), "w").write("1")
-    dist.barrier()
-    dist.destroy_process_group()
+    for b, (m0, a0, v0) in zip(eng.buckets, before):
+        assert torch.equal(b.master, m0) and torch.equal(b.exp_avg, a0) and torch.equal(b.exp_avg_sq, v0)
+    _done(rank, tmp)
 
 
 @pytest.mark.timeout(120)
 def test_sharded_engine_matches_single_process_adamw():
-    import socket
-
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
-        assert os.path.exists(os.path.join(tmp, "ok"))
+    _spawn(_worker_zero2)
 
 
+# --------------------------------------------------------------------------------------- unit hooks: zero2 and fsdp
+def _worker_units(rank, world, port, tmp, mode):
+    _init(rank, world, port)
+    from kai0_amd.sharded import ShardedDataParallel
+
+    model, ref = UnitStack(seed=3), UnitStack(seed=3)
+    eng = ShardedDataParallel(list(model.named_parameters()), world_size=world, rank=rank, ops=TorchShardOps(), weight_decay=0.0,
+                              max_grad_norm=1.0, bucket_bytes=1500, units=model.sharding_units(), mode=mode, prefetch=1)  # fmt: skip
+    model.hooks = eng
+    assert eng.mode == mode and len(eng.groups) >= 3
+    assert any(len(ids) == 2 for ids in eng.groups)  # a bf16 and an f32 bucket in one group
+    if mode == "fsdp":
+        assert all(b.flat_param.untyped_storage().nbytes() == 0 for b in eng.buckets)  # only shards persist
+    # the reference: f32 master weights + bf16 model copy, exactly what the engine maintains
+    rparams = [p for p in ref.parameters()]
+    masters = [p.detach().float().clone() for p in rparams]
+    exp_avg, exp_sq = [torch.zeros_like(m) for m in masters], [torch.zeros_like(m) for m in masters]
+    ops = TorchShardOps()
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(4, world, 3, 16, generator=g)
+    for step in range(4):
+        (model(data[step, rank]).pow(2).mean() / world).backward()
+        if mode == "fsdp":  # every group's parameters were dropped again as its gradients left
+            assert all(not eng.buckets[bi].resident for ids in eng.groups[:-1] for bi in ids)
+        norm = eng.step(3e-3)
+        ref.zero_grad()
+        ref(data[step].reshape(-1, 16)).pow(2).mean().backward()
+        grads = [p.grad for p in rparams]
+        tot = torch.sqrt(sum(gr.float().pow(2).sum() for gr in grads))
+        coef = torch.clamp(1.0 / (tot + 1e-6), max=1.0)
+        # bf16 gradients are summed by the collective in bf16: compare with a tolerance that covers one bf16 rounding
+        assert abs(float(norm) - float(tot)) < 2e-2 * float(tot)
+        for p, ms, a, v in zip(rparams, masters, exp_avg, exp_sq):
+            ops.adamw(ms, a, v, p.grad, p.data, lr=3e-3, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.0, step=step + 1, clip_coef=coef)
+        eng.wait_params()
+        for (n, p), r in zip(model.named_parameters(), rparams):
+            tol = 1e-2 if p.dtype == torch.bfloat16 else 2e-3
+            assert torch.allclose(p.float(), r.float(), atol=tol, rtol=tol), (mode, step, n, (p.float() - r.float()).abs().max())
+        if mode == "fsdp":
+            eng.release_params()
+            eng._issue_gather(0)
+    # replicas are identical
+    eng.wait_params()
+    flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    _done(rank, tmp)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("mode", ["zero2", "fsdp"])
+def test_unit_hooks_gather_per_unit(mode):
+    _spawn(_worker_units, 2, mode)
+
+
+# --------------------------------------------------------------------------------------- Trainer on the tiny pi0.5 model
+def _tiny_oracle_trainer(world, rank, mode="zero2"):
+    from tiny import tiny_cfgs
+
+    from kai0_amd.train import Trainer
+    from oracle.pi0_oracle import OraclePI0, synthetic_batch, synthetic_weights_
+
+    _, ocfg = tiny_cfgs()
+    model = OraclePI0(ocfg)  # the pure-torch restatement stands in for the HIP model: same parameter tree and dtypes
+    synthetic_weights_(model, seed=0)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(4.0)
+    tr = Trainer(model, world_size=world, rank=rank, peak_lr=1e-3, warmup_steps=2, decay_steps=10, end_lr=1e-4,
+                 shard_ops=TorchShardOps(), bucket_bytes=64 << 10, mode=mode)  # fmt: skip
+    obs, actions, noise, time = synthetic_batch(ocfg, 2, seed=0)
+    return tr, model, obs, actions, noise, time
+
+
+def _slice_obs(obs, i):
+    from oracle.pi0_oracle import SimpleObs
+
+    return SimpleObs(images={k: v[i : i + 1] for k, v in obs.images.items()}, image_masks={k: v[i : i + 1] for k, v in obs.image_masks.items()},
+                     state=obs.state[i : i + 1], tokenized_prompt=obs.tokenized_prompt[i : i + 1],
+                     tokenized_prompt_mask=obs.tokenized_prompt_mask[i : i + 1], token_ar_mask=None, token_loss_mask=None)  # fmt: skip
+
+
+def _worker_trainer(rank, world, port, tmp, ckpt):
+    _init(rank, world, port)
+    torch.set_num_threads(2)
+    tr, model, obs, actions, noise, time = _tiny_oracle_trainer(world, rank)
+    assert len(tr.engine.buckets) > 4
+    losses = []
+    for _ in range(2):
+        losses.append(float(tr.train_step(_slice_obs(obs, rank), actions[rank : rank + 1], noise[rank : rank + 1], time[rank : rank + 1])))
+    tr.save_checkpoint(ckpt)
+    if rank == 0:
+        assert sorted(os.listdir(os.path.join(ckpt, "2"))) == ["metadata.pt", "model.safetensors", "optimizer.pt"]
+    losses.append(float(tr.train_step(_slice_obs(obs, rank), actions[rank : rank + 1], noise[rank : rank + 1], time[rank : rank + 1])))
+    tr.params_ready()
+    torch.save({"losses": losses, "norm": float(tr.last_grad_norm), "params": {n: p.detach().float().clone() for n, p in model.named_parameters()}},
+               os.path.join(ckpt, f"w2_rank{rank}.pt"))  # fmt: skip
+    _done(rank, tmp)
+
+
+@pytest.mark.timeout(300)
+def test_trainer_world2_matches_world1_and_checkpoint_resumes_at_another_world_size(tmp_path):
+    ckpt = str(tmp_path)
+    _spawn(_worker_trainer, 2, ckpt)
+    w2 = [torch.load(os.path.join(ckpt, f"w2_rank{r}.pt"), weights_only=False) for r in range(2)]
+    for n in w2[0]["params"]:
+        assert torch.equal(w2[0]["params"][n], w2[1]["params"][n]), n  # replicas identical after 3 steps
+    # the same three global batches in ONE process
+    tr, model, obs, actions, noise, time = _tiny_oracle_trainer(1, 0)
+    init = {n: p.detach().float().clone() for n, p in model.named_parameters()}
+    l1 = [float(tr.train_step(obs, actions, noise, time)) for _ in range(3)]
+    mean_w2 = [(a + b) / 2 for a, b in zip(w2[0]["losses"], w2[1]["losses"])]
+    assert all(abs(a - b) < 2e-2 * abs(b) for a, b in zip(mean_w2, l1)), (mean_w2, l1)
+    assert abs(w2[0]["norm"] - float(tr.last_grad_norm)) < 5e-2 * float(tr.last_grad_norm)
+    num = den = 0.0
+    for n, p in model.named_parameters():
+        d1, d2 = p.detach().float() - init[n], w2[0]["params"][n] - init[n]
+        num += float((d1 - d2).pow(2).sum())
+        den += float(d1.pow(2).sum())
+    assert (num / den) ** 0.5 < 0.15, (num / den) ** 0.5  # bf16 gradients, B = 1 + 1 vs B = 2: same trajectory
+    # resume the world-2 checkpoint (step 2) on ONE rank: the third step lands where the two ranks landed
+    tr2, model2, *_ = _tiny_oracle_trainer(1, 0)
+    assert tr2.load_checkpoint(ckpt) == 2 and tr2.engine.step_count == 2
+    tr2.train_step(obs, actions, noise, time)
+    num = den = 0.0
+    for n, p in model2.named_parameters():
+        d1, d2 = p.detach().float() - init[n], w2[0]["params"][n] - init[n]
+        num += float((d1 - d2).pow(2).sum())
+        den += float(d2.pow(2).sum())
+    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
+
+
+# ------------------------------------------------------------------------------------------------------ single process
 def test_sharded_engine_world1_equals_reference():
     from kai0_amd.sharded import ShardedDataParallel
 
@@ -104,6 +297,51 @@ def test_sharded_engine_world1_equals_reference():
         ref(x).pow(2).mean().backward()
         torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
         ropt.step()
+    for p, r in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p, r, atol=2e-6, rtol=1e-5)
+
+
+def test_weights_written_after_construction_are_adopted_or_reported():
+    """ADVICE r1: the f32 master copies are cut at construction.  In-place writes + sync_master_from_params() are adopted;
+    rebinding p.data (a dtype cast, .to()) detaches the parameter from the flat buffer and the next step says so."""
+    from kai0_amd.sharded import ShardedDataParallel
+
+    model = _toy_model()
+    eng = ShardedDataParallel(list(model.named_parameters()), world_size=1, rank=0, ops=TorchShardOps(), weight_decay=0.0)
+    new = {n: torch.full_like(p, 0.25) for n, p in model.named_parameters()}
+    model.load_state_dict(new)  # in place: the views stay
+    eng.sync_master_from_params()
+    model(torch.ones(2, 24)).sum().backward()
+    eng.step(0.0)  # lr 0: the parameters must come back from the master copies unchanged
+    assert all(torch.equal(p, torch.full_like(p, 0.25)) for p in model.parameters())
+    model[0].weight.data = model[0].weight.data.clone()  # rebinding
+    model(torch.ones(2, 24)).sum().backward()
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        eng.step(1e-3)
+
+
+def test_reference_style_optimizer_state_loads():
+    """A plain torch.optim.AdamW state dict (the reference's optimizer.pt: indexed by position in model.parameters(), no master
+    copies, no names) resumes: moments by order, master copies from the parameters."""
+    from kai0_amd.sharded import ShardedDataParallel
+
+    ref = _toy_model()
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0)
+    x = torch.randn(4, 24)
+    ref(x).pow(2).mean().backward()
+    ropt.step()
+    model = _toy_model()
+    model.load_state_dict(ref.state_dict())
+    eng = ShardedDataParallel(list(model.named_parameters()), world_size=1, rank=0, ops=TorchShardOps(), weight_decay=0.0,
+                              max_grad_norm=None)  # fmt: skip
+    eng.load_state_dict(ropt.state_dict(), param_order=[n for n, _ in model.named_parameters()])
+    assert eng.step_count == 1
+    for step in range(2):
+        ref.zero_grad()
+        ref(x).pow(2).mean().backward()
+        ropt.step()
+        model(x).pow(2).mean().backward()
+        eng.step(1e-2)
     for p, r in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-5)
 
@@ -145,8 +383,9 @@ def test_flat_gradients_of_parameters_without_a_new_gradient_count_as_zero(monke
 
 
 def test_checkpoint_helpers_roundtrip_with_flat_buffers(tmp_path):
-    """Parameters that are views into flat buffers (as in the trainer) still save/load bit-exactly, tied weights once."""
-    from safetensors.torch import load_file
+    """Parameters that are views into flat buffers (as in the trainer) still save/load bit-exactly, tied weights once; a file
+    that holds NO member of a tied group does not pass as complete."""
+    from safetensors.torch import load_file, save_file
     from tiny import build_pair
 
     from kai0_amd.checkpoint import load_model_safetensors, save_model_safetensors
@@ -163,3 +402,8 @@ def test_checkpoint_helpers_roundtrip_with_flat_buffers(tmp_path):
     load_model_safetensors(model2, path)
     for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert a.dtype == b.dtype and torch.equal(a, b), k
+    broken = {k: v for k, v in raw.items() if "lm_head.weight" not in k or "gemma_expert" in k}
+    broken.pop(pw + "model.language_model.embed_tokens.weight", None)
+    save_file(broken, str(tmp_path / "broken.safetensors"))
+    with pytest.raises(RuntimeError, match="missing"):
+        load_model_safetensors(model2, str(tmp_path / "broken.safetensors"))
