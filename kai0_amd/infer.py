@@ -84,11 +84,22 @@ class InferenceEngine:
         return (batch, n_lang, n_cam) == (self.B, self.T, self.ncam) and self._weights_tag == self._fingerprint()
 
     def _fingerprint(self):
-        """Identity of the weights this engine (its stacked copies and its captured graph) was built from."""
+        """Identity of the weights this engine (its stacked copies and its captured graph) was built from: storage and
+        autograd version of every tensor a stacked copy was cut from, plus the count of optimizer updates made through the
+        HIP kernels (they write through raw pointers, which autograd's version counters do not see).  An in-place edit that
+        bypasses both (`p.data.copy_`, a foreign kernel) must be followed by `model.invalidate_inference_engine()`."""
+        from . import optim
+
         ex = self.pe.gemma_expert.model
+        vt = self.pe.paligemma.model.vision_tower.vision_model
+        lm = self.pe.paligemma.model.language_model
         srcs = [w for l in ex.layers for w in (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
                                                 l.mlp.gate_proj.weight, l.mlp.up_proj.weight)]  # fmt: skip
-        return tuple((p.data_ptr(), p._version) for p in srcs)
+        srcs += [w for l in lm.layers for w in (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight)]
+        for l in vt.encoder.layers:
+            at = l.self_attn
+            srcs += [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias]
+        return (optim.WEIGHT_UPDATES[0], *((p.data_ptr(), p._version) for p in srcs))
 
     def _build_stacked(self):
         """q|k|v weights (and biases) stacked once per engine: one GEMM launch per attention block instead of three.

@@ -28,8 +28,12 @@ def lr_schedule(step: int, *, warmup_steps: int, peak_lr: float, decay_steps: in
     return float(end_lr + (peak_lr - end_lr) * cos)
 
 
+WEIGHT_UPDATES = [0]  # bumped by every parameter update made through the HIP kernels (see infer.InferenceEngine._fingerprint)
+
+
 def adamw_step_(master, m, v, grad, param, *, lr, beta1, beta2, eps, wd, step: int, clip_coef=None):
     """One fused AdamW update of a flat f32 shard (kai0_adamw)."""
+    WEIGHT_UPDATES[0] += 1
     n = master.numel()
     bc1 = 1.0 - beta1**step
     bc2 = 1.0 - beta2**step
