@@ -121,6 +121,9 @@ typedef struct kai0_gemm_desc {
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
 /* sizeof(kai0_gemm_desc) as compiled: lets a foreign-language binding verify its struct mirror */
 int kai0_gemm_desc_size(void);
+/* Diagnostics: force a tile / schedule configuration of kai0_gemm_bf16 (0 = automatic choice, the default; values as the
+ * KAI0_GEMM_CFG environment variable, see gemm_bf16.hip).  Returns the previous setting.  Not thread-safe. */
+int kai0_gemm_set_cfg(int cfg);
 
 /* ------------------------------------------------------------------------------------------------
  * Few-row weight-streaming GEMM for the denoise loop (B*action_horizon <= a few 64-row tiles):

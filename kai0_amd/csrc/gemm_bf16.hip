@@ -237,9 +237,16 @@ __device__ __forceinline__ void lds_barrier() {
 // BKT = K-tile depth.  64 everywhere except the ring schedule (PP, NS = 4, BKT = 32): 4 slots of 32 KiB, three
 //   32-deep sub-tiles in flight, every load slot carries 2 DMA pieces + 12 fragment reads and every MFMA slot 32 MFMAs
 //   + 2 DMA pieces, with nothing conditional inside the loop (tail pieces are issued out of range = zero fill).
-template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64>
+// SCH (PP, NS = 2, BKT = 64, NT layout only): 0 = the two-buffer ping-pong below; 1 / 2 = the quadrant schedule ("8 phases" per
+//   two K-tiles): every K-tile is four phases of [fragment reads of one half-operand + 2 DMA pieces | barrier | 16 MFMAs of one
+//   64x32 quadrant of the wave's 128x64 sub-tile | barrier]; the four half-tiles of a K-tile (A rows / B columns of the two
+//   quadrant halves, 16 KiB each) are staged one per phase, 4-6 phases ahead of their first read, into the half-buffer whose
+//   previous occupant died earliest, with counted waits (never vmcnt(0) inside the loop).  1: pieces issued after the phase's
+//   fragment reads; 2: pieces issued in the middle of the phase's MFMAs.
+template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
+    static_assert(SCH == 0 || (PP && NS == 2 && BKT == 64 && A_KC && B_KC && MT == 8 && NT == 4), "quadrant schedule: NT 256x256x64");
     static_assert(NS >= 2 && (!PP || NS == 2 || (NS == 4 && BKT == 32)), "stages");
     static_assert(BKT == 64 || BKT == 32, "K-tile depth");
     constexpr int BK = BKT;
@@ -263,7 +270,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-
     // ---- block -> tile (XCD-aware bijective remap, then grouped raster) -------------------------
     const int nwg = gridDim.x;
     int pid = blockIdx.x;
@@ -476,6 +482,136 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             }
             __builtin_amdgcn_s_setprio(0);
             if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            lds_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill pieces must land before the slabs reuse LDS
+        if (grp == 0) lds_barrier();  // re-align the two groups
+        lds_barrier();
+    } else if constexpr (PP && SCH != 0) {
+        // Quadrant schedule.  Wave (wm, wn) owns rows wm*128 + [0, 128), columns wn*64 + [0, 64) of the tile; half-operand
+        // A_a = its rows a*64 + [0, 64) (for both wm: 128 tile rows), B_b = its columns b*32 + [0, 32) (for all four wn: 128 tile
+        // columns); 16 KiB = 16 DMA pieces each, two per wave.  Tile t (LDS slot t & 1) runs the quadrants
+        //     p0: (A0, B0)   p1: (A0, B1)   p2: (A1, B1)   p3: (A1, B0)
+        // reading A0 + B0 | B1 | A1 | B0 again, and issues  p0: B0(t+1)  p1: A1(t+1)  p2: A0(t+2)  p3: B1(t+2).
+        //  * WAR: each issue targets the half-buffer of a half-tile whose last read lies >= 1 barrier slot back for BOTH groups
+        //    (B0(t-1): p3 of t-1; A1(t-1): p2 of t-1; A0(t): p0 of t; B1(t): p1 of t; group 1 runs one slot behind group 0).
+        //  * RAW: p0 of t reads A0(t), B0(t): of the pieces issued so far only A1(t), A0(t+1), B1(t+1) are younger than B0(t),
+        //    so vmcnt(6) in the load part of p3 of t-1 (both groups, i.e. >= 1 barrier before any group's p0) retires them; p2
+        //    reads A1(t): younger are A0(t+1), B1(t+1), B0(t+1), A1(t+1) -> vmcnt(8) in the load part of p1.  The prologue
+        //    issues what tiles -2 and -1 would have, in the same order, so the counts hold from the first tile; pieces past
+        //    the last tile are issued out of range (zero fill into half-buffers nobody reads), so they hold in the tail too.
+        const int grp = wm;
+        uint32_t ha_off[4], hb_off[4];  // idx = half * 2 + j
+        int ha_rb[4], hb_rb[4];         // first tile row of the piece (wave-uniform)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * wave + j;
+                const int ra = (q >> 3) * 128 + h * 64 + (q & 7) * 8, rb = (q >> 2) * 64 + h * 32 + (q & 3) * 8;
+                const int Ra = m0 + ra + (lane >> 3), Rb = n0 + rb + (lane >> 3);
+                ha_rb[h * 2 + j] = ra;
+                hb_rb[h * 2 + j] = rb;
+                ha_off[h * 2 + j] = Ra < p.M ? (uint32_t)((p.amap(Ra) * p.lda + kc_chunk) * 2) : OOB;
+                hb_off[h * 2 + j] = Rb < p.N ? (uint32_t)((p.bmap(Rb) * p.ldb + kc_chunk) * 2) : OOB;
+            }
+        auto issue_half = [&](bool isb, int h, int t) {
+            const int k0 = kbeg + t * BK;
+            const bool kc_in = (k0 + kc_chunk) < kend;
+            char* base = smem + (t & 1) * STAGE + (isb ? A_TILE : 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t o = isb ? hb_off[h * 2 + j] : ha_off[h * 2 + j];
+                const uint32_t off = (kc_in && o != OOB && p.ablate != 1) ? o + (uint32_t)k0 * 2 : OOB;
+                glds16(isb ? b_rsrc : a_rsrc, off, base + (isb ? hb_rb[h * 2 + j] : ha_rb[h * 2 + j]) * 128);
+            }
+        };
+        issue_half(false, 0, 0);
+        issue_half(true, 1, 0);
+        issue_half(true, 0, 0);
+        issue_half(false, 1, 0);
+        issue_half(false, 0, 1);
+        issue_half(true, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        lds_barrier();
+        if (grp == 1) lds_barrier();  // stagger group 1 by one slot
+        bf16x8 af[4][2], bq[2][2];
+        auto read_a = [&](const char* ta, int h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag(ta, true, A_ROWB, wm * 128 + (h * 4 + i) * 16, ks);
+        };
+        auto read_b = [&](const char* tb, int h) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bq[j][ks] = load_frag(tb, true, B_ROWB, wn * 64 + (h * 2 + j) * 16, ks);
+        };
+        // 16 MFMAs of quadrant (ah, bh); SCH == 2: the phase's two DMA pieces go out after the 8th
+        auto quad = [&](auto ahc, auto bhc, bool isb, int h, int t) {
+            constexpr int ah = decltype(ahc)::value, bh = decltype(bhc)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bq[j][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                if (SCH == 2 && ks == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_half(isb, h, t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        for (int t = 0; t < nk; ++t) {
+            const char* ta = smem + (t & 1) * STAGE;
+            const char* tb = ta + A_TILE;
+            // ---- p0: (A0, B0); stage B0(t+1)
+            read_b(tb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(ta, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (SCH == 1) issue_half(true, 0, t + 1);
+            lds_barrier();
+            quad(I0{}, I0{}, true, 0, t + 1);
+            lds_barrier();
+            // ---- p1: (A0, B1); stage A1(t+1); A1(t) must have landed one phase from now
+            read_b(tb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (SCH == 1) {
+                issue_half(false, 1, t + 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {  // the phase's own pieces are not issued yet: one half-tile fewer in flight
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+            lds_barrier();
+            quad(I0{}, I1{}, false, 1, t + 1);
+            lds_barrier();
+            // ---- p2: (A1, B1); stage A0(t+2) (same slot as this tile: A0(t) died in p0)
+            read_a(ta, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (SCH == 1) issue_half(false, 0, t + 2);
+            lds_barrier();
+            quad(I1{}, I1{}, false, 0, t + 2);
+            lds_barrier();
+            // ---- p3: (A1, B0); stage B1(t+2); A0(t+1), B0(t+1) must have landed one phase from now
+            read_b(tb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (SCH == 1) {
+                issue_half(true, 1, t + 2);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            lds_barrier();
+            quad(I1{}, I0{}, true, 1, t + 2);
             lds_barrier();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill pieces must land before the slabs reuse LDS
@@ -722,7 +858,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-template <int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64>
+template <int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
     constexpr int LDS = NS * (TBM + TBN) * BKT * 2;
@@ -732,7 +868,7 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
 #define KAI0_LAUNCH(AK, BK_)                                                                                      \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
-        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS, BKT>;                                              \
+        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS, BKT, (AK && BK_) ? SCH : 0>;                       \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             if (e != hipSuccess) {                                                                                \
@@ -757,7 +893,15 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     return 0;
 }
 
+int g_gemm_cfg = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
+
 }  // namespace
+
+KAI0_API int kai0_gemm_set_cfg(int cfg) {
+    const int old = g_gemm_cfg;
+    g_gemm_cfg = cfg;
+    return old;
+}
 
 KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d != nullptr, "kai0_gemm_bf16: null descriptor");
@@ -849,7 +993,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     }
     // tile configuration: 256x256 (1 block of 8 waves per CU, half the staged bytes per FLOP) when the problem gives
     // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
-    static const int forced = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
+    const int forced = g_gemm_cfg;
     const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch * (split > 1 ? split : 1);
     const bool big = forced ? forced >= 4 : (big_tiles >= 160 && d->K >= 256);
     hipStream_t s = (hipStream_t)stream;
@@ -866,9 +1010,15 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // every line crosses the fabric twice), which keeps the two-buffer ping-pong.
     const bool ring = forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc);
     // forced 8: 384x256x64 plain loop (NT / NN only): 20 % fewer staged bytes per FLOP than 256x256
+    // forced 9 / 10: the quadrant schedule for NT (DMA pieces after the fragment reads / between the MFMAs), others as picked
     if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
+    else if (forced == 9 && d->a_kc && d->b_kc) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
+    else if (forced == 10 && d->a_kc && d->b_kc) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);
     else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
+    // NT: quadrant schedule (measured +6..10 % over the two-buffer ping-pong on every pi0.5 shape, 1.37 PFLOP/s at 8192^3);
+    // KAI0_GEMM_CFG=5 forces the former for all layouts
+    else if (big && d->b_kc && forced != 5) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
     else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);
     else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);
