@@ -1129,6 +1129,20 @@ def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H
     return att, probs
 
 
+_ATTN_BWD_NT = os.environ.get("KAI0_ATTN_BWD_NT", "1") != "0"
+_ATTN_BWD_SPLIT = os.environ.get("KAI0_ATTN_BWD_SPLIT", "auto")
+
+
+def _attn_bwd_split(Bn: int, S_ld: int, HD: int, M: int) -> int:
+    """Split of the row contraction of dV = P^T dO / dK = dS^T Q so that (256x256 tiles) x batch x split fills the chip once."""
+    if _ATTN_BWD_SPLIT != "auto":
+        return int(_ATTN_BWD_SPLIT)
+    t256 = ((S_ld + 255) // 256) * ((HD + 255) // 256) * Bn
+    if t256 >= 160 or M < 4096:
+        return 1
+    return max(1, min(8, -(-256 // t256), M // 2048))
+
+
 class JointAttentionFn(torch.autograd.Function):
     """The shared attention of one joint layer (gemma_pytorch.py:165-219): concat the per-expert q/k/v over the
     sequence, RoPE, prefix-LM masked MQA attention, split back.
@@ -1188,9 +1202,12 @@ class JointAttentionFn(torch.autograd.Function):
             _copy_rows(douts[i].contiguous(), datt, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
             r0 += Li
         # dV[b] [S_ld, HD] = P[b]^T [S_ld, M] @ dO[b] [M, HD]
+        # (few output tiles per sample, long contraction over the M = S*H folded rows: split it so that the 256x256 ring
+        # schedule gets a block per CU instead of falling back to 128x128 tiles — 578 -> ~1000 TFLOP/s)
+        kv_split = _attn_bwd_split(Bn, S_ld, HD, M)
         dv_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
-             sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
+             sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0), split_k=kv_split)  # fmt: skip
         # dS[b] [M, S_ld] = softmax'(dP), dP[b] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K]): the softmax
         # backward runs in the GEMM epilogue on the f32 accumulator (dP is never rounded or written; the row term
         # <dP, P> is computed as rowsum(dO * O), kai0hip.h act 4)
@@ -1200,12 +1217,19 @@ class JointAttentionFn(torch.autograd.Function):
              sB=(S_ld * HD, 0), sC=(M * S_ld, 0), act=4, aux1=probs, rowvec=dsum, rv=(S_ld * H, 0, 1), scale=scale)  # fmt: skip
         # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
         dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-        gemm(dscores, k_all, dq_all, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
-             sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0))  # fmt: skip
+        if _ATTN_BWD_NT and S_ld % 8 == 0:
+            # through K^T (0.5 MB per sample to transpose): both operands contraction-contiguous -> the NT quadrant schedule
+            kt = torch.empty((Bn, HD, S_ld), dtype=BF16, device=dev)
+            transpose_strided(k_all, kt, R=S_ld, C=HD, src_ld=HD, dst_ld=S_ld, batch=Bn, src_bs=S_ld * HD, dst_bs=HD * S_ld)
+            gemm(dscores, kt, dq_all, M=M, N=HD, K=S_ld, lda=S_ld, ldb=S_ld, ldc=HD, batch=Bn, sA=(M * S_ld, 0),
+                 sB=(HD * S_ld, 0), sC=(S_ld * H * HD, 0))  # fmt: skip
+        else:
+            gemm(dscores, k_all, dq_all, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
+                 sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0))  # fmt: skip
         # dK[b] [S_ld, HD] = dS[b]^T [S_ld, M] @ Q[b] [M, HD]
         dk_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(dscores, q_all, dk_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
-             sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0))  # fmt: skip
+             sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0), split_k=kv_split)  # fmt: skip
         grads = []
         r0 = 0
         for Li in seg_lens:
