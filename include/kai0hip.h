@@ -169,6 +169,16 @@ typedef struct kai0_skinny_desc {
     int32_t rope_half, _pad;
     void* workspace;
     int64_t workspace_bytes;
+    /* split_k == -1: the whole contraction inside one block (K / 256 waves, K in {1024, 2048, 4096}): no partial products, the
+     * full epilogue in the same launch.  Modes 1 and 2 as above; mode 0 then tiles N in 16-column blocks (pair_stride ignored)
+     * and the row tiles of one column tile share the weight slice through one XCD's L2.  With `mod` set (modes 1, 2; K == the
+     * row width D) the A operand is adaRMS-normalised on the fly: y = bf16((x * rstd) * (1 + scale) + shift), rstd =
+     * rsqrt(mean(x^2) + eps) over the row, scale = mod[b][0:D], shift = mod[b][D:2D], b = row / mod_rpb (modeling_gemma.py:49-104):
+     * the norm between the residual stream and the projection needs no launch of its own. */
+    const float* mod;
+    int64_t mod_ld;
+    int32_t mod_rpb;
+    float eps;
 } kai0_skinny_desc;
 
 int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stream);

@@ -78,6 +78,7 @@ class SkinnyDesc(C.Structure):
         ("gate", c_p), ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64),
         ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("_pad", C.c_int32),
         ("workspace", c_p), ("workspace_bytes", c_i64),
+        ("mod", c_p), ("mod_ld", c_i64), ("mod_rpb", C.c_int32), ("eps", c_f),
     ]  # fmt: skip
 
 

@@ -59,10 +59,104 @@ struct SkinnyArgs {
     const float* rope_sin;
     int rope_half;
     float* ws;
+    const float* mod;  // adaRMS prologue (skinny2 only): scale = mod[b*mod_ld + k], shift = mod[b*mod_ld + K + k]
+    int mod_rpb;
+    int64_t mod_ld;
+    float eps;
 };
 
 constexpr int TM = 64, TN = 32;
 constexpr int RED_LD = TN + 1;  // f32 row stride of a wave's partial tile in LDS (odd: conflict-free column writes)
+
+// The fused epilogue on this thread's 4 + 4 outputs: v0 = columns n0 .. n0+3, v1 = columns n1 .. n1+3 (n1 = n0 + pair_stride; only
+// v0 when `pair` is false) of output row `mrow` (f32 sums over the whole contraction).  Rounding points: see kai0hip.h.
+__device__ __forceinline__ void sk_epilogue(const SkinnyArgs& p, float (&v0)[4], float (&v1)[4], int mrow, int n0, int n1, bool pair) {
+    const int64_t orow = p.cmap(mrow);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v0[e] = rbf(v0[e]);
+        v1[e] = rbf(v1[e]);
+    }
+    if (p.mode == 2) {  // GeGLU: v0 = gate pre-activation, v1 = up
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(gelu_tanh_f(v0[e])) * v1[e]);
+        *reinterpret_cast<bf16x4*>(p.seg[0].dst + orow * p.seg[0].ld + n0) = o;
+        return;
+    }
+    if (p.mode == 1) {  // column segments, optional rotation
+        int si = 0;
+        if (p.nseg > 1 && n0 >= p.seg[1].n_begin) si = 1;
+        if (p.nseg > 2 && n0 >= p.seg[2].n_begin) si = 2;
+        const SkSeg sg = p.seg[si];
+        const int c0 = n0 - sg.n_begin;
+        bf16x4 o1, o2;
+        if (sg.rope == 1) {
+            const int d = c0 % (2 * p.rope_half);  // index inside the head, < rope_half by construction
+            const float* ct = p.rope_cos + (int64_t)mrow * p.rope_half + d;
+            const float* st = p.rope_sin + (int64_t)mrow * p.rope_half + d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = ct[e], s = st[e];
+                o1[e] = f2bf(rbf(v0[e] * c) + rbf(-v1[e] * s));
+                o2[e] = f2bf(rbf(v1[e] * c) + rbf(v0[e] * s));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o1[e] = f2bf(v0[e]);
+                o2[e] = f2bf(v1[e]);
+            }
+        }
+        if (sg.rope == 2) {
+            // transposed destination [batch][cols][ld] (value cache of kai0_attn_decode): element (row, col) -> dst[col][row]
+            const int bq = p.cmap.rpb ? mrow / p.cmap.rpb : 0;
+            const int64_t srow = p.cmap.rpb ? (int64_t)(mrow - bq * p.cmap.rpb) + p.cmap.off : (int64_t)mrow;
+            bf16_t* dp = sg.dst + (int64_t)bq * (sg.n_end - sg.n_begin) * sg.ld + (int64_t)c0 * sg.ld + srow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dp[(int64_t)e * sg.ld] = o1[e];
+                dp[(int64_t)(e + p.pair_stride) * sg.ld] = o2[e];
+            }
+            return;
+        }
+        bf16_t* dp = sg.dst + orow * sg.ld + c0;
+        *reinterpret_cast<bf16x4*>(dp) = o1;
+        *reinterpret_cast<bf16x4*>(dp + p.pair_stride) = o2;
+        return;
+    }
+    if (p.gate != nullptr) {
+        const bf16_t* gp = p.gate + (int64_t)(mrow / p.gate_rpb) * p.gate_ld;
+        const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(gp + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v0[e] = rbf(v0[e] * bf2f(g0[e]));
+        if (pair) {
+            const bf16x4 g1 = *reinterpret_cast<const bf16x4*>(gp + n1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v1[e] = rbf(v1[e] * bf2f(g1[e]));
+        }
+    }
+    if (p.residual != nullptr) {
+        const bf16_t* rp = p.residual + orow * p.ldr;
+        const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(rp + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v0[e] = rbf(v0[e] + bf2f(r0[e]));
+        if (pair) {
+            const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(rp + n1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v1[e] = rbf(v1[e] + bf2f(r1[e]));
+        }
+    }
+    bf16x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o1[e] = f2bf(v0[e]);
+        o2[e] = f2bf(v1[e]);
+    }
+    bf16_t* dp = p.seg[0].dst + orow * p.seg[0].ld;
+    *reinterpret_cast<bf16x4*>(dp + n0) = o1;
+    if (pair) *reinterpret_cast<bf16x4*>(dp + n1) = o2;
+}
 
 // NW waves share the block's K range (k_blk / NW each, NC chunks of 128): 4 x 2 chunks or 8 x 1 chunk for k_blk = 1024
 // (twice the waves = twice the loads in flight per CU for the launches that cannot split K over blocks), 4 x 1 for 512.
@@ -159,90 +253,173 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny_kernel(const SkinnyArgs p) 
     // ---- epilogue --------------------------------------------------------------------------------------
     const int mrow = m0 + row;
     if (mrow >= p.M) return;
-    const int64_t orow = p.cmap(mrow);
-    const int n0 = n_sub0 + 4 * q, n1 = n_sub1 + 4 * q;
+    sk_epilogue(p, v0, v1, mrow, n_sub0 + 4 * q, n_sub1 + 4 * q, true);
+}
+
+// skinny2: the whole contraction inside ONE block (no partial products, no combine launch): NW = K / 256 waves (4, 8 or 16),
+// each with 256 of K (two chunks of 128), every load of the block in flight at once, wave partials summed through LDS, the full
+// epilogue in the same launch.  N / 32 (PAIR: two 16-column groups `pair_stride` apart, modes 0-2) or N / 16 blocks (!PAIR:
+// mode 0) — a 1024-column o_proj / down_proj is 64 blocks of 64-128 KB of weights each: the launch is one memory latency long,
+// which is what matters for a 50-row GEMM; the former split-K version needed its partials finished by a separate launch.
+//   ADA: the A operand is adaRMS-normalised on the fly (K == D, the block's waves hold complete rows): y = bf16((x * rstd) *
+//   (1 + scale) + shift), rstd over the row, scale / shift from `mod` — the norm that kai0_adarms_combine applied in a launch
+//   of its own (modeling_gemma.py:49-104).
+//   MTL = 16-row tiles per block: 4 (all 64 rows; the weight slice is read once) for the wide q|k|v and gate|up launches, 1 for the
+//   1024-column o_proj / down_proj, whose 64 column tiles alone would leave three quarters of the chip idle: their four row
+//   tiles run as four blocks with the same blockIdx.x, i.e. on the same XCD (block -> XCD is linear id % 8 and gridDim.x % 8 == 0),
+//   so the weight slice crosses the fabric once and is shared through that XCD's L2.
+//   NC = 128-wide chunks of K per wave (K = NW * NC * 128): 2 normally, 1 for the adaRMS variant (half the fragment registers per
+//   wave, twice the waves).
+template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true>
+__global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p) {
+    constexpr int TMB = 16 * MTL;
+    constexpr int TN2 = PAIR ? 32 : 16;
+    constexpr int LD2 = TN2 + 1;
+    extern __shared__ __attribute__((aligned(16))) char sk2_smem[];
+    float (*red)[TMB][LD2] = reinterpret_cast<float (*)[TMB][LD2]>(sk2_smem);
+    float (*ssq)[TMB] = reinterpret_cast<float (*)[TMB]>(sk2_smem + sizeof(float) * NW * TMB * LD2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, mt_blk = blockIdx.z;
+    int n_sub0, n_sub1;
+    if constexpr (PAIR) {
+        const int per = p.pair_stride >> 4;
+        n_sub0 = (tile / per) * (2 * p.pair_stride) + (tile % per) * 16;
+        n_sub1 = n_sub0 + p.pair_stride;
+    } else {
+        n_sub0 = tile * 16;
+        n_sub1 = n_sub0;
+    }
+    // ADA: row tiles never straddle two batch entries (one scale / shift vector per tile): tile z covers rows
+    // b * rpb + [t * TMB, (t + 1) * TMB) of entry b = z / tiles_per_entry
+    int m0 = mt_blk * TMB, m_end = p.M;
+    if constexpr (ADA) {
+        const int tpe = (p.mod_rpb + TMB - 1) / TMB, b = mt_blk / tpe;
+        m0 = b * p.mod_rpb + (mt_blk - b * tpe) * TMB;
+        m_end = min(p.M, (b + 1) * p.mod_rpb);
+    }
+    const int kw0 = wave * (NC * 128);
+
+    // contraction index of (lane group g, load j, element e) inside a 128-chunk: 32 j + 8 g + e — the four lanes of a row fetch one
+    // contiguous 64-byte sector per load instruction (the same permutation for A, W and the modulation vectors)
+    const bf16_t* w0 = p.W + (int64_t)(n_sub0 + i) * p.ldw + kw0 + 8 * g;
+    const bf16_t* w1 = p.W + (int64_t)(n_sub1 + i) * p.ldw + kw0 + 8 * g;
+    const bf16_t* arow[MTL];
+    bool aok[MTL];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) {
+        const int r = m0 + mt * 16 + i;
+        aok[mt] = r < m_end;
+        arow[mt] = p.A + p.amap(aok[mt] ? r : 0) * p.lda + kw0 + 8 * g;
+    }
+    bf16x8 wf[NC][PAIR ? 2 : 1][4], af[NC][MTL][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // WNT: streamed once by this block only -> non-temporal; shared by the row-tile blocks of an XCD -> keep it in L2
+            if constexpr (WNT) {
+                wf[c][0][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w0 + c * 128 + 32 * j));
+                if constexpr (PAIR) wf[c][1][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + c * 128 + 32 * j));
+            } else {
+                wf[c][0][j] = *reinterpret_cast<const bf16x8*>(w0 + c * 128 + 32 * j);
+                if constexpr (PAIR) wf[c][1][j] = *reinterpret_cast<const bf16x8*>(w1 + c * 128 + 32 * j);
+            }
+        }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                af[c][mt][j] = aok[mt] ? *reinterpret_cast<const bf16x8*>(arow[mt] + c * 128 + 32 * j) : zero8;
+
+    if constexpr (ADA) {
+        // row statistics: this wave's 256 of the row's K = D elements, then the NW waves' partials through LDS (fixed order)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = bf2f(af[c][mt][j][e]);
+                        ss += x * x;
+                    }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (g == 0) ssq[wave][mt * 16 + i] = ss;
+        }
+        __syncthreads();
+        float rstd[MTL];
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) {
+            float ss = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) ss += ssq[w][mt * 16 + i];
+            rstd[mt] = rsqrtf(ss / (float)p.K + p.eps);
+        }
+        const float* mrow = p.mod + (int64_t)(m0 / p.mod_rpb) * p.mod_ld + kw0 + 8 * g;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* mp = mrow + c * 128 + 32 * j;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(mp), a1 = *reinterpret_cast<const f32x4*>(mp + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(mp + p.K), b1 = *reinterpret_cast<const f32x4*>(mp + p.K + 4);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt) {
+                    bf16x8 y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        y[e] = f2bf((bf2f(af[c][mt][j][e]) * rstd[mt]) * (1.0f + (e < 4 ? a0[e] : a1[e - 4])) + (e < 4 ? b0[e] : b1[e - 4]));
+                    af[c][mt][j] = aok[mt] ? y : zero8;
+                }
+            }
+    }
+
+    f32x4 acc[MTL][PAIR ? 2 : 1];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+        for (int s2 = 0; s2 < (PAIR ? 2 : 1); ++s2) acc[mt][s2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int s2 = 0; s2 < (PAIR ? 2 : 1); ++s2)
+                    acc[mt][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c][mt][j], wf[c][s2][j], acc[mt][s2], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+        for (int s2 = 0; s2 < (PAIR ? 2 : 1); ++s2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][mt * 16 + 4 * g + r][s2 * 16 + i] = acc[mt][s2][r];
+    __syncthreads();
+    if (tid >= TMB * 4) return;  // TMB rows x 4 column quads finish the tile
+    const int row = tid >> 2, q = tid & 3;
+    float v0[4], v1[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        v0[e] = rbf(v0[e]);
-        v1[e] = rbf(v1[e]);
-    }
-    if (p.mode == 2) {  // GeGLU: v0 = gate pre-activation, v1 = up
-        bf16x4 o;
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(gelu_tanh_f(v0[e])) * v1[e]);
-        *reinterpret_cast<bf16x4*>(p.seg[0].dst + orow * p.seg[0].ld + n0) = o;
-        return;
-    }
-    if (p.mode == 1) {  // column segments, optional rotation
-        int si = 0;
-        if (p.nseg > 1 && n0 >= p.seg[1].n_begin) si = 1;
-        if (p.nseg > 2 && n0 >= p.seg[2].n_begin) si = 2;
-        const SkSeg sg = p.seg[si];
-        const int c0 = n0 - sg.n_begin;
-        bf16x4 o1, o2;
-        if (sg.rope == 1) {
-            const int d = c0 % (2 * p.rope_half);  // index inside the head, < rope_half by construction
-            const float* ct = p.rope_cos + (int64_t)mrow * p.rope_half + d;
-            const float* st = p.rope_sin + (int64_t)mrow * p.rope_half + d;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float c = ct[e], s = st[e];
-                o1[e] = f2bf(rbf(v0[e] * c) + rbf(-v1[e] * s));
-                o2[e] = f2bf(rbf(v1[e] * c) + rbf(v0[e] * s));
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o1[e] = f2bf(v0[e]);
-                o2[e] = f2bf(v1[e]);
-            }
+        for (int w = 0; w < NW; ++w) {
+            s0 += red[w][row][4 * q + e];
+            if constexpr (PAIR) s1 += red[w][row][16 + 4 * q + e];
         }
-        if (sg.rope == 2) {
-            // transposed destination [batch][cols][ld] (value cache of kai0_attn_decode): element (row, col) -> dst[col][row]
-            const int bq = p.cmap.rpb ? mrow / p.cmap.rpb : 0;
-            const int64_t srow = p.cmap.rpb ? (int64_t)(mrow - bq * p.cmap.rpb) + p.cmap.off : (int64_t)mrow;
-            bf16_t* dp = sg.dst + (int64_t)bq * (sg.n_end - sg.n_begin) * sg.ld + (int64_t)c0 * sg.ld + srow;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                dp[(int64_t)e * sg.ld] = o1[e];
-                dp[(int64_t)(e + p.pair_stride) * sg.ld] = o2[e];
-            }
-            return;
-        }
-        bf16_t* dp = sg.dst + orow * sg.ld + c0;
-        *reinterpret_cast<bf16x4*>(dp) = o1;
-        *reinterpret_cast<bf16x4*>(dp + p.pair_stride) = o2;
-        return;
+        v0[e] = s0;
+        v1[e] = s1;
     }
-    if (p.gate != nullptr) {
-        const bf16_t* gp = p.gate + (int64_t)(mrow / p.gate_rpb) * p.gate_ld;
-        const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(gp + n0);
-        const bf16x4 g1 = *reinterpret_cast<const bf16x4*>(gp + n1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v0[e] = rbf(v0[e] * bf2f(g0[e]));
-            v1[e] = rbf(v1[e] * bf2f(g1[e]));
-        }
-    }
-    if (p.residual != nullptr) {
-        const bf16_t* rp = p.residual + orow * p.ldr;
-        const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(rp + n0);
-        const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(rp + n1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v0[e] = rbf(v0[e] + bf2f(r0[e]));
-            v1[e] = rbf(v1[e] + bf2f(r1[e]));
-        }
-    }
-    bf16x4 o1, o2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        o1[e] = f2bf(v0[e]);
-        o2[e] = f2bf(v1[e]);
-    }
-    bf16_t* dp = p.seg[0].dst + orow * p.seg[0].ld;
-    *reinterpret_cast<bf16x4*>(dp + n0) = o1;
-    *reinterpret_cast<bf16x4*>(dp + n1) = o2;
+    const int mrow = m0 + row;
+    if (mrow >= m_end) return;
+    sk_epilogue(p, v0, v1, mrow, n_sub0 + 4 * q, n_sub1 + 4 * q, PAIR);
 }
 
 __global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restrict__ pos, const float* __restrict__ inv_freq,
@@ -265,15 +442,81 @@ KAI0_API int64_t kai0_skinny_workspace_bytes(int M, int N, int split_k) {
     return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
 }
 
+namespace {
+
+template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true>
+int launch_skinny2(const SkinnyArgs& a, hipStream_t s) {
+    constexpr int TMB = 16 * MTL, LD2 = (PAIR ? 32 : 16) + 1;
+    constexpr int LDS = (int)sizeof(float) * NW * TMB * (LD2 + 1);
+    static_assert(LDS <= 160 * 1024, "skinny2: LDS");
+    // ADA: row tiles per batch entry (see the kernel)
+    const int mtiles = ADA ? ((a.M + a.mod_rpb - 1) / a.mod_rpb) * ((a.mod_rpb + TMB - 1) / TMB) : (a.M + TMB - 1) / TMB;
+    const dim3 grid(a.N / (PAIR ? 32 : 16), 1, mtiles);
+    auto kern = skinny2_kernel<NW, MTL, PAIR, ADA, NC, WNT>;
+    if constexpr (LDS > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            KAI0_REQUIRE(e == hipSuccess, "kai0_gemm_skinny_bf16: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS, s, a);
+    return kai0_check_launch("kai0_gemm_skinny_bf16 (in-block K)");
+}
+
+// split_k == -1: skinny2 (see kai0hip.h)
+int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
+    const int nw = d->K / 256;  // waves of the two-chunk variants
+    KAI0_REQUIRE(d->K % 256 == 0 && (nw == 4 || nw == 8 || nw == 16), "kai0_gemm_skinny_bf16: in-block K needs K in {1024, 2048, 4096}, got %d", d->K);
+    const bool ada = d->mod != nullptr;
+    if (ada) {
+        KAI0_REQUIRE(d->mode != 0 && nw == 4 && d->mod_rpb > 0 && d->mod_ld >= 2 * (int64_t)d->K && d->mod_ld % 4 == 0 &&
+                         ((uintptr_t)d->mod % 16) == 0 && d->a_rpb == 0,
+                     "kai0_gemm_skinny_bf16: the adaRMS prologue needs mode 1 / 2, K = 1024, mod [b][>= 2K] f32 16-byte aligned, identity A rows");
+        a.mod = d->mod;
+        a.mod_ld = d->mod_ld;
+        a.mod_rpb = d->mod_rpb;
+        a.eps = d->eps;
+    }
+    if (d->mode == 0) {
+        KAI0_REQUIRE(d->N % 128 == 0, "kai0_gemm_skinny_bf16: in-block mode 0 needs N %% 128 == 0 (8 column tiles per XCD round), got %d", d->N);
+        a.pair_stride = 16;
+        // One 16-row tile per block, cached (not non-temporal) weight loads: the four row-tile blocks of a column tile share the
+        // slice through their XCD's L2.  Measured in the chunk (us per launch, K = 2048 / 4096): 6.9 / 10.3; with non-temporal loads
+        // (each block streams its own copy from the fabric) 8.6 / 13.9; two row tiles per block 8.8 / 14.1; all four in one block
+        // (weights once, 1024-thread blocks) 13.4 / 33.
+        static const int variant = [] { const char* e = getenv("KAI0_SK2_VARIANT"); return e ? atoi(e) : 0; }();
+        if (variant == 1) {  // half the waves, four chunks of K each
+            if (nw == 8) return launch_skinny2<4, 1, false, false, 4, false>(a, s);
+            if (nw == 16) return launch_skinny2<8, 1, false, false, 4, false>(a, s);
+        }
+        if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false>(a, s);
+        if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false>(a, s);
+        return launch_skinny2<16, 1, false, false, 2, false>(a, s);
+    }
+    KAI0_REQUIRE(nw == 4, "kai0_gemm_skinny_bf16: in-block modes 1 / 2 are built for K = 1024 (got %d)", d->K);
+    static const int pv_all = [] { const char* e = getenv("KAI0_SK2_PAIR_VARIANT"); return e ? atoi(e) : 30; }();
+    const int pv = d->mode == 1 ? pv_all / 10 : pv_all % 10;  // tens digit: q|k|v launch, ones digit: gate|up launch
+    if (ada && pv == 1) return launch_skinny2<8, 2, true, true, 1, false>(a, s);
+    if (ada && pv == 2) return launch_skinny2<8, 1, true, true, 1, false>(a, s);
+    if (ada && pv == 3) return launch_skinny2<4, 2, true, true, 2, false>(a, s);
+    if (ada && pv == 4) return launch_skinny2<4, 1, true, true, 2, false>(a, s);
+    return ada ? launch_skinny2<8, 4, true, true, 1>(a, s) : launch_skinny2<4, 4, true, false>(a, s);
+}
+
+}  // namespace
+
 KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d != nullptr && d->A && d->W, "kai0_gemm_skinny_bf16: null operand");
     KAI0_REQUIRE(d->M >= 1 && d->N >= 32 && d->N % 32 == 0, "kai0_gemm_skinny_bf16: M=%d N=%d unsupported", d->M, d->N);
+    const bool inblock = d->split_k == -1;
     const int S = d->split_k < 1 ? 1 : d->split_k;
-    KAI0_REQUIRE(d->K % S == 0 && ((d->K / S) == 512 || (d->K / S) == 1024),
+    KAI0_REQUIRE(inblock || (d->K % S == 0 && ((d->K / S) == 512 || (d->K / S) == 1024)),
                  "kai0_gemm_skinny_bf16: K=%d split_k=%d: K/split_k must be 512 or 1024", d->K, S);
     KAI0_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && ((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0,
                  "kai0_gemm_skinny_bf16: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
-    const int ps = d->pair_stride;
+    const int ps = (inblock && d->mode == 0) ? 16 : d->pair_stride;
     KAI0_REQUIRE(ps >= 16 && ps % 16 == 0 && d->N % (2 * ps) == 0, "kai0_gemm_skinny_bf16: pair_stride=%d does not tile N=%d",
                  ps, d->N);
     KAI0_REQUIRE(d->mode >= 0 && d->mode <= 2, "kai0_gemm_skinny_bf16: mode=%d", d->mode);
@@ -318,6 +561,8 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
     a.rope_cos = d->rope_cos;
     a.rope_sin = d->rope_sin;
     a.rope_half = d->rope_half > 0 ? d->rope_half : ps;
+    if (inblock) return skinny_inblock(d, a, (hipStream_t)stream);
+    KAI0_REQUIRE(d->mod == nullptr, "kai0_gemm_skinny_bf16: the adaRMS prologue needs split_k == -1");
     const int tiles = d->N / TN, mtiles = (d->M + TM - 1) / TM;
     if (S > 1) {
         const int64_t need = (int64_t)S * d->M * d->N * 4;

@@ -29,6 +29,11 @@ from .ops import BF16, F32, gemm, pick_split_k, round_up
 logger = logging.getLogger("kai0_amd")
 
 
+def NQ_ok(nq: int) -> bool:
+    """contraction widths the in-block skinny kernel takes (K / 256 waves)"""
+    return nq in (1024, 2048, 4096)
+
+
 def euler_times(num_steps: int) -> list[float]:
     """The t values visited by `while time >= -dt/2` with f32 accumulation (pi0_pytorch.py:401-419)."""
     dt = np.float32(-1.0 / num_steps)
@@ -99,6 +104,8 @@ class InferenceEngine:
         for l in vt.encoder.layers:
             at = l.self_attn
             srcs += [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias]
+        srcs += [m for l in ex.layers for m in (l.input_layernorm.dense.weight, l.post_attention_layernorm.dense.weight)]
+        srcs.append(ex.norm.dense.weight)
         return (optim.WEIGHT_UPDATES[0], *((p.data_ptr(), p._version) for p in srcs))
 
     def _build_stacked(self):
@@ -184,6 +191,13 @@ class InferenceEngine:
         self.S_o, self.S_d = ops.skinny_split_k(De, H * HD), ops.skinny_split_k(De, self.F)
         self.ws_o = ops.skinny_workspace(M, De, self.S_o, dev)
         self.ws_d = ops.skinny_workspace(M, De, self.S_d, dev)
+        # (superseded for K in {1024, 2048, 4096}: the in-block kernels below need neither partial products nor a combine launch)
+        self.inblock = (os.environ.get("KAI0_INFER_INBLOCK", "1") != "0" and De == 1024 and NQ_ok(H * HD) and self.F in (1024, 2048, 4096)
+                        and De % 128 == 0)  # fmt: skip
+        # all 37 adaRMS `dense` layers stacked: the modulations of every layer and step come out of ONE f32 GEMM
+        dens = [m for l in ex.layers for m in (l.input_layernorm.dense, l.post_attention_layernorm.dense)] + [ex.norm.dense]
+        self.w_mod = torch.cat([m.weight for m in dens], 0).contiguous()
+        self.b_mod = torch.cat([m.bias for m in dens], 0).contiguous()
         # one-launch decode attention: needs the value cache transposed ([HD][keys])
         self.decode_attn = HD == 256 and self.S <= 1024 and self.P % 8 == 0
         if self.decode_attn:
@@ -273,7 +287,8 @@ class InferenceEngine:
             xp = ops.linear_fwd(hmid, layer.mlp.down_proj.weight, residual=xp)
 
     def _modulations(self, times: list[float]):
-        """time embedding -> time MLP -> adaRMS `dense` for every step at once (rows = step*B + b)."""
+        """time embedding -> time MLP -> adaRMS `dense` for every layer and step at once (rows = step*B + b): one f32 GEMM over
+        the 37 stacked `dense` weights.  Returns per-layer views (row stride 37 * 3 De) and the final norm's."""
         model, B, De = self.model, self.B, self.De
         n = len(times)
         tt = self._times_dev[tuple(times)]
@@ -281,14 +296,57 @@ class InferenceEngine:
         _lib.call("kai0_time_sincos", tt.data_ptr(), te.data_ptr(), n * B, De, 4e-3, 4.0, ops._stream())
         x = ops.silu_f32(ops.linear_f32(te, model.time_mlp_in.weight, model.time_mlp_in.bias))
         cond = ops.silu_f32(ops.linear_f32(x, model.time_mlp_out.weight, model.time_mlp_out.bias))
-        ex = self.pe.gemma_expert.model
-        mods = []
-        for layer in ex.layers:
-            m1 = ops.linear_f32(cond, layer.input_layernorm.dense.weight, layer.input_layernorm.dense.bias)
-            m2 = ops.linear_f32(cond, layer.post_attention_layernorm.dense.weight, layer.post_attention_layernorm.dense.bias)
-            mods.append((m1, m2))
-        mf = ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
-        return mods, mf
+        if not self.skinny:
+            ex = self.pe.gemma_expert.model
+            mods = [(ops.linear_f32(cond, l.input_layernorm.dense.weight, l.input_layernorm.dense.bias),
+                     ops.linear_f32(cond, l.post_attention_layernorm.dense.weight, l.post_attention_layernorm.dense.bias))
+                    for l in ex.layers]  # fmt: skip
+            return mods, ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
+        allm = ops.linear_f32(cond, self.w_mod, self.b_mod)  # [n*B, 37 * 3 De]
+        self._mod_ld = allm.shape[1]
+        self._gates = ops.cast(allm, BF16)  # gate = bf16(third chunk): taken as views, row stride _mod_ld
+        W3 = 3 * De
+        mods = [(allm[:, (2 * l) * W3 : (2 * l + 1) * W3], allm[:, (2 * l + 1) * W3 : (2 * l + 2) * W3]) for l in range(self.L)]
+        return mods, allm[:, 2 * self.L * W3 :]
+
+    def _gate(self, idx: int, rows):
+        """bf16 gate vector(s) of stacked modulation `idx` (2 l: input norm, 2 l + 1: post-attention norm) for `rows`."""
+        De = self.De
+        c0 = idx * 3 * De + 2 * De
+        return self._gates[rows, c0 : c0 + De]
+
+    def _expert_stack_inblock(self, xs, mods, mf, rows):
+        """All expert layers of one denoise step, 6 launches per layer and no partial products: [adaRMS -> q|k|v + RoPE],
+        logits, softmax + P V, [o_proj + gated residual], [adaRMS -> gate|up + GeGLU], [down_proj + gated residual].  The norms
+        run as prologues of the projections that consume them; the gates are precomputed for all steps (`_gate`)."""
+        B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
+        M, dev = B * Hs, self.dev
+        cos, sin = self._rope_cs
+        layers = self.pe.gemma_expert.model.layers
+        NQ = H * HD
+        ld = self._mod_ld
+        for l, layer in enumerate(layers):
+            ops.skinny_gemm(xs, self.w_qkv[l], M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2, split_k=-1,
+                            segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
+                                  (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
+                            c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, mod=mods[l][0][rows], mod_ld=ld,
+                            mod_rpb=Hs, eps=layer.input_layernorm.eps)  # fmt: skip
+            ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
+                            rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
+                            vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
+            x1 = torch.empty((M, De), dtype=BF16, device=dev)
+            ops.skinny_gemm(self.att_buf, layer.self_attn.o_proj.weight, M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
+                            a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
+                            residual=xs, ldr=De)  # fmt: skip
+            h = torch.empty((M, F), dtype=BF16, device=dev)
+            ops.skinny_gemm(x1, self.w_gu[l], M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
+                            segs=[(h, F, 0, F, 0)], mod=mods[l][1][rows], mod_ld=ld, mod_rpb=Hs,
+                            eps=layer.post_attention_layernorm.eps)  # fmt: skip
+            xs = torch.empty((M, De), dtype=BF16, device=dev)
+            ops.skinny_gemm(h, layer.mlp.down_proj.weight, M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
+                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De)  # fmt: skip
+        out, _ = ops.adarms(xs, mf[rows].contiguous(), Hs, self.pe.gemma_expert.model.norm.eps)
+        return out
 
     def _expert_stack_skinny(self, xs, mods, mf, rows):
         """All expert layers of one denoise step, 8 launches per layer: q|k|v+RoPE, logits, softmax, P V (+reduce),
@@ -299,7 +357,8 @@ class InferenceEngine:
         cos, sin = self._rope_cs
         layers = self.pe.gemma_expert.model.layers
         NQ = H * HD
-        hs, gate1 = ops.adarms(xs, mods[0][0][rows], Hs, layers[0].input_layernorm.eps)
+        cm = lambda t: t[rows].contiguous()  # noqa: E731 - the stacked modulations are strided views
+        hs, gate1 = ops.adarms(xs, cm(mods[0][0]), Hs, layers[0].input_layernorm.eps)
         for l, layer in enumerate(layers):
             ops.skinny_gemm(hs, self.w_qkv[l], M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2,
                             segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
@@ -314,12 +373,12 @@ class InferenceEngine:
                 self._attend(l, P, Hs, P + Hs, self.qcode, self.kcode)
             ops.skinny_gemm(self.att_buf, layer.self_attn.o_proj.weight, M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=self.S_o,
                             workspace=self.ws_o, a_map=(Hs, S_ld, P))  # fmt: skip
-            x1, hs, gate2 = ops.adarms_combine(self.ws_o, gate1, xs, mods[l][1][rows], Hs, layer.post_attention_layernorm.eps)
+            x1, hs, gate2 = ops.adarms_combine(self.ws_o, gate1, xs, cm(mods[l][1]), Hs, layer.post_attention_layernorm.eps)
             h = torch.empty((M, F), dtype=BF16, device=dev)
             ops.skinny_gemm(hs, self.w_gu[l], M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, segs=[(h, F, 0, F, 0)])
             ops.skinny_gemm(h, layer.mlp.down_proj.weight, M=M, N=De, K=F, lda=F, ldw=F, split_k=self.S_d, workspace=self.ws_d)
             last = l + 1 == len(layers)
-            nmod = mf[rows] if last else mods[l + 1][0][rows]
+            nmod = cm(mf) if last else cm(mods[l + 1][0])
             neps = self.pe.gemma_expert.model.norm.eps if last else layers[l + 1].input_layernorm.eps
             xs, hs, gate1 = ops.adarms_combine(self.ws_d, gate2, x1, nmod, Hs, neps)
         return hs  # = final adaRMS norm of the last residual stream
@@ -334,7 +393,8 @@ class InferenceEngine:
         xs = ops.cast(a, BF16)
         rows = slice(step * B, (step + 1) * B)
         if self.skinny:
-            out = self._expert_stack_skinny(xs, mods, mf, rows)
+            stack = self._expert_stack_inblock if (self.inblock and self.decode_attn) else self._expert_stack_skinny
+            out = stack(xs, mods, mf, rows)
             v = ops.linear_f32(ops.cast(out, F32), model.action_out_proj.weight, model.action_out_proj.bias)
             return v.view(B, Hs, self.A)
         for l, layer in enumerate(ex.layers):

@@ -132,8 +132,10 @@ def skinny_workspace(M: int, N: int, split_k: int, device) -> torch.Tensor:
 
 def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int = 0, pair_stride: int = 16, segs=None,
                 split_k: int = 1, workspace=None, a_map=None, c_map=None, gate=None, gate_rpb: int = 0, gate_ld: int = 0,
-                residual=None, ldr: int = 0, rope_cos=None, rope_sin=None, rope_half: int = 0):  # fmt: skip
-    """kai0_gemm_skinny_bf16.  segs = [(dst, ld, n_begin, n_end, rope)]."""
+                residual=None, ldr: int = 0, rope_cos=None, rope_sin=None, rope_half: int = 0, mod=None, mod_ld: int = 0,
+                mod_rpb: int = 0, eps: float = 1e-6):  # fmt: skip
+    """kai0_gemm_skinny_bf16.  segs = [(dst, ld, n_begin, n_end, rope)].  split_k = -1: the whole contraction inside one block
+    (no partial products); with `mod` (f32 view [b][>= 2K], row stride mod_ld) the A operand is adaRMS-normalised on the fly."""
     for t in (A, W):
         if not t.is_cuda or t.dtype != BF16:
             raise _lib.Kai0HipError("skinny_gemm: expected bf16 CUDA (HIP) tensors; the product path has no CPU fallback")
@@ -160,6 +162,10 @@ def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int =
         if workspace is None or workspace.dtype != F32:
             raise _lib.Kai0HipError("skinny_gemm: split_k > 1 writes f32 partial products into `workspace` (skinny_workspace)")
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * 4
+    if mod is not None:
+        if mod.dtype != F32 or not mod.is_cuda or mod.stride(-1) != 1:
+            raise _lib.Kai0HipError("skinny_gemm: mod must be an f32 CUDA (HIP) tensor with unit inner stride")
+        d.mod, d.mod_ld, d.mod_rpb, d.eps = mod.data_ptr(), mod_ld, mod_rpb, eps
     _lib.call("kai0_gemm_skinny_bf16", C.byref(d), _stream())
 
 

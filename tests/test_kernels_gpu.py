@@ -891,3 +891,83 @@ def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
     O.backward(do.float().view(n, S, NH, HD).transpose(1, 2))
     for got, ref, name in zip(outs[True][1:], (Q.grad, K.grad, V.grad), ("dq", "dk", "dv")):
         assert rel_err(got.view(n, S, NH, HD).transpose(1, 2), ref) < 1.5e-2, name
+
+
+# ------------------------------------------------------------------------------- in-block skinny GEMMs (split_k = -1)
+@pytest.mark.parametrize("M,K,N", [(50, 2048, 1024), (50, 4096, 1024), (100, 4096, 1024), (50, 1024, 1024), (7, 2048, 128)])
+def test_skinny_inblock_plain_gate_residual(ops, M, K, N):
+    """o_proj / down_proj of the denoise loop in ONE launch: whole contraction inside a block (K / 256 waves), 16-row x 16-column
+    tiles, gated residual in the epilogue == kai0_gemm_bf16 with the same fused epilogue (same rounding points)."""
+    rpb, S_ld, row0 = (50 if M % 50 == 0 else M), 72, 11
+    nb = M // rpb
+    a_buf = rnd(nb * S_ld, K, seed=1)
+    w = rnd(N, K, seed=2, scale=0.05)
+    gate_all = rnd(nb, 3 * N, seed=3)  # gate taken as a strided view (row stride 3 N), as the engine does
+    gate = gate_all[:, 2 * N :]
+    res = rnd(M, N, seed=4)
+    ref = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a_buf, w, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_map=(rpb, S_ld, row0), gate=gate.contiguous(), gate_rpb=rpb,
+             gate_ld=N, residual=res, ldr=N)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), dtype=BF16, device=dev())
+        ops.skinny_gemm(a_buf, w, M=M, N=N, K=K, lda=K, ldw=K, split_k=-1, segs=[(out, N, 0, N, 0)], a_map=(rpb, S_ld, row0),
+                        gate=gate, gate_rpb=rpb, gate_ld=3 * N, residual=res, ldr=N)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
+    rows = torch.cat([torch.arange(rpb) + b * S_ld + row0 for b in range(nb)]).to(dev())
+    y = (a_buf[rows].float() @ w.float().t()).to(BF16).float()
+    y = (y * gate.float().repeat_interleave(rpb, 0)).to(BF16).float()
+    y = (y + res.float()).to(BF16)
+    assert_close_bf16(outs[0], y.float(), what="skinny in-block plain", tol=1e-2)
+    assert rel_err(outs[0], ref) < 2e-3
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_skinny_inblock_adarms_prologue(ops, B):
+    """[adaRMS -> q|k|v + RoPE] and [adaRMS -> gate|up + GeGLU] as single launches == kai0_adarms_fwd followed by the plain
+    skinny GEMM of the same mode (the norm's row statistics are summed in another order: equal up to rare one-ulp flips)."""
+    Hs, P, S_ld, H, HD, K, F = 50, 30, 88, 8, 256, 1024, 4096
+    M = B * Hs
+    x = rnd(M, K, seed=1)
+    mod_all = rnd(B, 5 * 3 * K, dtype=F32, seed=9, scale=0.3)  # stacked modulations: take slot 3 as a strided view
+    mod = mod_all[:, 3 * 3 * K : 4 * 3 * K]
+    y_ref, _ = ops.adarms(x, mod.contiguous(), Hs, 1e-6)
+    wqkv = rnd((H + 2) * HD, K, seed=2, scale=0.05)
+    pos = (torch.arange(M, device=dev(), dtype=torch.int32) % Hs + 700).view(B, Hs).contiguous()
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, HD, 2, device=dev(), dtype=F32) / HD))).to(BF16).float()
+    cos, sin = ops.rope_table(pos, inv_freq)
+    N = (H + 2) * HD
+
+    def qkv(a, **kw):
+        q = torch.zeros(B, S_ld, H * HD, dtype=BF16, device=dev())
+        k = torch.zeros(B, S_ld, HD, dtype=BF16, device=dev())
+        vt = torch.zeros(B, HD, S_ld, dtype=BF16, device=dev())
+        ops.skinny_gemm(a, wqkv, M=M, N=N, K=K, lda=K, ldw=K, mode=1, pair_stride=HD // 2,
+                        segs=[(q, H * HD, 0, H * HD, 1), (k, HD, H * HD, H * HD + HD, 1), (vt, S_ld, H * HD + HD, N, 2)],
+                        c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, **kw)
+        return q, k, vt
+
+    ref = qkv(y_ref)
+    got = qkv(x, split_k=-1, mod=mod, mod_ld=mod_all.shape[1], mod_rpb=Hs, eps=1e-6)
+    for a, b, name in zip(got, ref, ("q", "k", "vt")):
+        assert rel_err(a, b) < 2e-3, (name, rel_err(a, b))
+        assert float((a != b).float().mean()) < 2e-2, name
+    assert torch.equal(got[0][:, :P], ref[0][:, :P]) and torch.equal(got[2][:, :, :P], ref[2][:, :, :P])  # untouched rows
+    # and against fp32 math of the whole thing
+    xf = x.float().view(B, Hs, K)
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    yn = ((xf * rstd) * (1 + mod[:, None, :K]) + mod[:, None, K : 2 * K]).to(BF16).float().view(M, K)
+    v32 = (yn @ wqkv[(H + 1) * HD :].float().t()).view(B, Hs, HD)
+    assert rel_err(got[2][:, :, P : P + Hs].transpose(1, 2), v32) < 6e-3
+    wgu = rnd(2 * F, K, seed=3, scale=0.05)
+    h_ref = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(y_ref, wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, segs=[(h_ref, F, 0, F, 0)])
+    h = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, split_k=-1, segs=[(h, F, 0, F, 0)], mod=mod,
+                    mod_ld=mod_all.shape[1], mod_rpb=Hs, eps=1e-6)
+    assert rel_err(h, h_ref) < 3e-3 and float((h != h_ref).float().mean()) < 3e-2
+    # the in-block kernel without the prologue on the already normalised input: the same products in another summation order
+    h2 = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(y_ref, wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, split_k=-1, segs=[(h2, F, 0, F, 0)])
+    assert rel_err(h2, h_ref) < 2e-3 and float((h2 != h_ref).float().mean()) < 2e-2
