@@ -220,3 +220,80 @@ def torch_to_jax(sd: Mapping[str, torch.Tensor], *, num_heads: int = 8, num_kv_h
             out[f"{name}/kernel"] = _np(sd[name + ".weight"]).T
             out[f"{name}/bias"] = _np(sd[name + ".bias"])
     return out
+
+
+# ------------------------------------------------------------------------------------------ Orbax directory I/O (optional)
+def restore_params(params_path, *, dtype=None) -> dict:
+    """`openpi.models.model.restore_params(params_path, restore_type=np.ndarray)` (models/model.py:319-365): the `params` item of
+    an Orbax PyTree checkpoint as a nested dict of numpy arrays, the trailing "value" level that `nnx.State` adds to every
+    leaf of training checkpoints removed.  Needs `orbax-checkpoint` (not part of this image: the import is deferred, and
+    everything downstream — `jax_to_torch`, the safetensors writer — works on the returned tree without it)."""
+    import pathlib
+
+    try:
+        import orbax.checkpoint as ocp  # type: ignore
+    except ImportError as e:
+        raise ImportError("restore_params reads Orbax checkpoints and needs the `orbax-checkpoint` package (pip install "
+                          "orbax-checkpoint); alternatively export the tree with numpy on a machine that has it and pass the "
+                          "dict to kai0_amd.convert.jax_to_torch") from e  # fmt: skip
+    params_path = pathlib.Path(params_path).resolve()
+
+    def tree_map(fn, t):
+        return {k: tree_map(fn, v) for k, v in t.items()} if isinstance(t, Mapping) else fn(t)
+
+    with ocp.PyTreeCheckpointer() as ckptr:
+        metadata = ckptr.metadata(params_path)
+        item = {"params": metadata["params"]}
+        restore_args = tree_map(lambda _: ocp.ArrayRestoreArgs(restore_type=np.ndarray, dtype=dtype), item)
+        params = ckptr.restore(params_path, ocp.args.PyTreeRestore(item=item, restore_args=restore_args))["params"]
+    flat = flatten_params(params)
+    if flat and all(k.split("/")[-1] == "value" for k in flat):
+        flat = {k.rsplit("/", 1)[0]: v for k, v in flat.items()}
+    out: dict = {}
+    for k, v in flat.items():
+        node = out
+        parts = k.split("/")
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        node[parts[-1]] = np.asarray(v)
+    return out
+
+
+def convert_checkpoint(jax_checkpoint_dir, out_dir, *, precision: str = "bfloat16", config=None) -> str:
+    """JAX checkpoint directory (`<dir>/params` Orbax tree, `<dir>/assets` norm stats) -> torch checkpoint directory
+    (`model.safetensors` + `assets/`) that `create_trained_policy` / `Trainer.load_checkpoint` read.  The state dict goes
+    through the model once (`load_state_dict(strict=True)` + `to_bfloat16_for_selected_params`), so key set, shapes and storage
+    dtypes are those of the contract."""
+    import pathlib
+    import shutil
+
+    from .checkpoint import save_model_safetensors
+    from .config import Pi0Config
+    from .model import PI0Pytorch
+
+    src, dst = pathlib.Path(jax_checkpoint_dir), pathlib.Path(out_dir)
+    tree = restore_params(src / "params")
+    cfg = config or Pi0Config()
+    sd = jax_to_torch(tree, fill_missing=True, vocab_size=cfg.vocab_size)
+    with torch.device("meta"):
+        model = PI0Pytorch(cfg)
+    model.to_empty(device="cpu")
+    model.load_state_dict({k: v.to(model.state_dict()[k].dtype) if precision == "bfloat16" else v for k, v in sd.items()},
+                          strict=True)  # fmt: skip
+    model.paligemma_with_expert.to_bfloat16_for_selected_params(precision)
+    dst.mkdir(parents=True, exist_ok=True)
+    save_model_safetensors(model, str(dst / "model.safetensors"))
+    if (src / "assets").exists():
+        shutil.copytree(src / "assets", dst / "assets", dirs_exist_ok=True)
+    return str(dst)
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser(description="Convert an openpi JAX checkpoint (params + assets) into a torch checkpoint directory")
+    ap.add_argument("jax_checkpoint_dir")
+    ap.add_argument("out_dir")
+    ap.add_argument("--precision", default="bfloat16", choices=["bfloat16", "float32"])
+    a = ap.parse_args()
+    print(convert_checkpoint(a.jax_checkpoint_dir, a.out_dir, precision=a.precision))

@@ -237,7 +237,7 @@ __device__ __forceinline__ void lds_barrier() {
 // BKT = K-tile depth.  64 everywhere except the ring schedule (PP, NS = 4, BKT = 32): 4 slots of 32 KiB, three
 //   32-deep sub-tiles in flight, every load slot carries 2 DMA pieces + 12 fragment reads and every MFMA slot 32 MFMAs
 //   + 2 DMA pieces, with nothing conditional inside the loop (tail pieces are issued out of range = zero fill).
-// SCH (PP, NS = 2, BKT = 64, NT layout only): 0 = the two-buffer ping-pong below; 1 / 2 = the quadrant schedule ("8 phases" per
+// SCH (PP, NS = 2, BKT = 64): 0 = the two-buffer ping-pong below; 1 / 2 = the quadrant schedule ("8 phases" per
 //   two K-tiles): every K-tile is four phases of [fragment reads of one half-operand + 2 DMA pieces | barrier | 16 MFMAs of one
 //   64x32 quadrant of the wave's 128x64 sub-tile | barrier]; the four half-tiles of a K-tile (A rows / B columns of the two
 //   quadrant halves, 16 KiB each) are staged one per phase, 4-6 phases ahead of their first read, into the half-buffer whose
@@ -246,7 +246,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
-    static_assert(SCH == 0 || (PP && NS == 2 && BKT == 64 && A_KC && B_KC && MT == 8 && NT == 4), "quadrant schedule: NT 256x256x64");
+    static_assert(SCH == 0 || (PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4), "quadrant schedule: 256x256x64");
     static_assert(NS >= 2 && (!PP || NS == 2 || (NS == 4 && BKT == 32)), "stages");
     static_assert(BKT == 64 || BKT == 32, "K-tile depth");
     constexpr int BK = BKT;
@@ -500,20 +500,44 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         //    reads A1(t): younger are A0(t+1), B1(t+1), B0(t+1), A1(t+1) -> vmcnt(8) in the load part of p1.  The prologue
         //    issues what tiles -2 and -1 would have, in the same order, so the counts hold from the first tile; pieces past
         //    the last tile are issued out of range (zero fill into half-buffers nobody reads), so they hold in the tail too.
+        //  * Contraction-strided operands ([K][M] / [K][N] in memory, ds_read_b64_tr_b16 fragments): a half-operand is 128
+        //    CONSECUTIVE rows / columns of the tile (a 256-B run per k-row: whole cache lines), staged as an image [64 k][128]
+        //    with the usual key swizzle, 4 k-rows per DMA piece; the waves' sub-tiles are interleaved accordingly — wave wm
+        //    owns rows a*128 + wm*64 + [0, 64), a = 0, 1 (wave wn: columns b*128 + wn*32 + [0, 32)) — and the epilogue maps
+        //    its accumulators back through the same formula (ILM / ILN below).
         const int grp = wm;
-        uint32_t ha_off[4], hb_off[4];  // idx = half * 2 + j
-        int ha_rb[4], hb_rb[4];         // first tile row of the piece (wave-uniform)
+        uint32_t ha_off[4], hb_off[4];  // idx = half * 2 + j: byte offset of this lane's 16 B (without the K-tile term)
+        int ha_lds[4], hb_lds[4];       // LDS byte offset of the piece inside its operand tile (wave-uniform)
+        int ha_kr[4], hb_kr[4];         // contraction-strided: this lane's k-row inside the K-tile
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int q = 2 * wave + j;
-                const int ra = (q >> 3) * 128 + h * 64 + (q & 7) * 8, rb = (q >> 2) * 64 + h * 32 + (q & 3) * 8;
-                const int Ra = m0 + ra + (lane >> 3), Rb = n0 + rb + (lane >> 3);
-                ha_rb[h * 2 + j] = ra;
-                hb_rb[h * 2 + j] = rb;
-                ha_off[h * 2 + j] = Ra < p.M ? (uint32_t)((p.amap(Ra) * p.lda + kc_chunk) * 2) : OOB;
-                hb_off[h * 2 + j] = Rb < p.N ? (uint32_t)((p.bmap(Rb) * p.ldb + kc_chunk) * 2) : OOB;
+                const int q = 2 * wave + j, x = h * 2 + j;
+                if constexpr (A_KC) {
+                    const int ra = (q >> 3) * 128 + h * 64 + (q & 7) * 8, Ra = m0 + ra + (lane >> 3);
+                    ha_lds[x] = ra * 128;
+                    ha_kr[x] = 0;
+                    ha_off[x] = Ra < p.M ? (uint32_t)((p.amap(Ra) * p.lda + kc_chunk) * 2) : OOB;
+                } else {
+                    const int r = q * 4 + (lane >> 4), key = (r & 3) | (((r >> 3) & 1) << 2);
+                    const int col = m0 + h * 128 + (((lane & 15) ^ (key << 1)) * 8);
+                    ha_lds[x] = h * 16384 + q * 1024;
+                    ha_kr[x] = r;
+                    ha_off[x] = col < p.M ? (uint32_t)(col * 2) : OOB;
+                }
+                if constexpr (B_KC) {
+                    const int rb = (q >> 2) * 64 + h * 32 + (q & 3) * 8, Rb = n0 + rb + (lane >> 3);
+                    hb_lds[x] = rb * 128;
+                    hb_kr[x] = 0;
+                    hb_off[x] = Rb < p.N ? (uint32_t)((p.bmap(Rb) * p.ldb + kc_chunk) * 2) : OOB;
+                } else {
+                    const int r = q * 4 + (lane >> 4), key = (r & 3) | (((r >> 3) & 1) << 2);
+                    const int col = n0 + h * 128 + (((lane & 15) ^ (key << 1)) * 8);
+                    hb_lds[x] = h * 16384 + q * 1024;
+                    hb_kr[x] = r;
+                    hb_off[x] = col < p.N ? (uint32_t)(col * 2) : OOB;
+                }
             }
         auto issue_half = [&](bool isb, int h, int t) {
             const int k0 = kbeg + t * BK;
@@ -521,9 +545,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             char* base = smem + (t & 1) * STAGE + (isb ? A_TILE : 0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const uint32_t o = isb ? hb_off[h * 2 + j] : ha_off[h * 2 + j];
-                const uint32_t off = (kc_in && o != OOB && p.ablate != 1) ? o + (uint32_t)k0 * 2 : OOB;
-                glds16(isb ? b_rsrc : a_rsrc, off, base + (isb ? hb_rb[h * 2 + j] : ha_rb[h * 2 + j]) * 128);
+                const int x = h * 2 + j;
+                const uint32_t o = isb ? hb_off[x] : ha_off[x];
+                uint32_t off = OOB;
+                if (isb ? B_KC : A_KC) {
+                    if (kc_in && o != OOB) off = o + (uint32_t)k0 * 2;
+                } else {
+                    const int kr = k0 + (isb ? hb_kr[x] : ha_kr[x]);
+                    if (kr < kend && o != OOB) off = o + (uint32_t)(isb ? p.bmap(kr) : p.amap(kr)) * (isb ? ldb2 : lda2);
+                }
+                if (p.ablate == 1) off = OOB;
+                glds16(isb ? b_rsrc : a_rsrc, off, base + (isb ? hb_lds[x] : ha_lds[x]));
             }
         };
         issue_half(false, 0, 0);
@@ -540,13 +572,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag(ta, true, A_ROWB, wm * 128 + (h * 4 + i) * 16, ks);
+                for (int ks = 0; ks < 2; ++ks)
+                    af[i][ks] = A_KC ? load_frag(ta, true, A_ROWB, wm * 128 + (h * 4 + i) * 16, ks)
+                                     : load_frag(ta + h * 16384, false, 256, wm * 64 + i * 16, ks);
         };
         auto read_b = [&](const char* tb, int h) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bq[j][ks] = load_frag(tb, true, B_ROWB, wn * 64 + (h * 2 + j) * 16, ks);
+                for (int ks = 0; ks < 2; ++ks)
+                    bq[j][ks] = B_KC ? load_frag(tb, true, B_ROWB, wn * 64 + (h * 2 + j) * 16, ks)
+                                     : load_frag(tb + h * 16384, false, 256, wn * 32 + j * 16, ks);
         };
         // 16 MFMAs of quadrant (ah, bh); SCH == 2: the phase's two DMA pieces go out after the 8th
         auto quad = [&](auto ahc, auto bhc, bool isb, int h, int t) {
@@ -704,7 +740,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int64_t vz = z1 * p.rv_s1 + z2 * p.rv_s2;
-    const int ccol = n0 + wn * 64 + (lane & 7) * 8;
+    // quadrant schedule with a contraction-strided operand: that operand's sub-tiles are interleaved (see the schedule)
+    constexpr bool ILM = SCH != 0 && !A_KC, ILN = SCH != 0 && !B_KC;
+    const int ccol = ILN ? n0 + ((lane & 7) >> 2) * 128 + wn * 32 + ((lane & 7) & 3) * 8 : n0 + wn * 64 + (lane & 7) * 8;
+    auto row_base = [&](int h) { return ILM ? m0 + h * 128 + wm * 64 : m0 + wm * (MT * 16) + h * 64; };
     // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
     // zero-filled) and are stored into the row padding the host guarantees (ldc >= round_up(N, 8)).
     const bool col_ok = ccol < ((p.N + 7) & ~7);
@@ -721,7 +760,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         if (fused_fast) {
             bf16x8 s0[8], s1[8];
             float ds[8];
-            const int rbase = m0 + wm * (MT * 16) + h * 64 + (lane >> 3);
+            const int rbase = row_base(h) + (lane >> 3);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = rbase + it * 8;
@@ -812,7 +851,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
 #pragma unroll 1
         for (int it = 0; it < 8; ++it) {
             const int lr = it * 8 + (lane >> 3);
-            const int row = m0 + wm * (MT * 16) + h * 64 + lr;
+            const int row = row_base(h) + lr;
             if (row >= p.M || !col_ok) continue;
             const float* sp = slab + lr * 64 + (lane & 7) * 8;
             f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
@@ -868,7 +907,7 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
 #define KAI0_LAUNCH(AK, BK_)                                                                                      \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
-        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS, BKT, (AK && BK_) ? SCH : 0>;                       \
+        auto kern = gemm_bf16_kernel<AK, BK_, WM, WN, MT, NT, PP, NS, BKT, SCH>;                       \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             if (e != hipSuccess) {                                                                                \
@@ -1012,8 +1051,8 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // forced 8: 384x256x64 plain loop (NT / NN only): 20 % fewer staged bytes per FLOP than 256x256
     // forced 9 / 10: the quadrant schedule for NT (DMA pieces after the fragment reads / between the MFMAs), others as picked
     if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
-    else if (forced == 9 && d->a_kc && d->b_kc) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
-    else if (forced == 10 && d->a_kc && d->b_kc) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);
+    else if (forced == 9) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
+    else if (forced == 10) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);
     else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     // NT: quadrant schedule (measured +6..10 % over the two-buffer ping-pong on every pi0.5 shape, 1.37 PFLOP/s at 8192^3);

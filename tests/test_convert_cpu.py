@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -137,3 +138,73 @@ def test_converted_weights_drive_the_model_to_the_same_loss():
     obs, actions, noise, time = O.synthetic_batch(ocfg, 2, seed=1)
     with torch.no_grad():
         assert torch.equal(a(obs, actions, noise, time), b(obs, actions, noise, time))
+
+
+def test_restore_params_and_convert_checkpoint_with_a_stub_orbax(tmp_path, monkeypatch):
+    """`restore_params` / `convert_checkpoint` against a stand-in for orbax.checkpoint (absent in this image) that serves a
+    training-style tree (every leaf wrapped in {"value": ...}, as nnx.State saves it): the suffix is stripped, the tree goes
+    through jax_to_torch into the model, and the written directory is what create_trained_policy reads."""
+    import sys
+    import types
+
+    import numpy as np
+    from tiny import tiny_cfgs
+
+    from kai0_amd import convert
+    from kai0_amd.model import PI0Pytorch
+
+    pcfg, _ = tiny_cfgs()
+    torch.manual_seed(3)
+    src_model = PI0Pytorch(pcfg)
+    tree_flat = convert.torch_to_jax(src_model.state_dict(), num_heads=8, num_kv_heads=1, siglip_heads=pcfg.siglip.num_heads)
+    nested: dict = {}
+    for k, v in tree_flat.items():
+        node = nested
+        parts = k.split("/")
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        node[parts[-1]] = {"value": v}
+
+    class _Ckptr:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def metadata(self, path):
+            assert str(path).endswith("params")
+            return {"params": nested, "opt_state": {}}
+
+        def restore(self, path, args):
+            assert set(args.item) == {"params"}
+            return {"params": args.item["params"]}
+
+    stub = types.ModuleType("orbax.checkpoint")
+    stub.PyTreeCheckpointer = _Ckptr
+    stub.ArrayRestoreArgs = lambda **kw: kw
+    stub.args = types.SimpleNamespace(PyTreeRestore=lambda item, restore_args: types.SimpleNamespace(item=item, restore_args=restore_args))
+    pkg = types.ModuleType("orbax")
+    pkg.checkpoint = stub
+    monkeypatch.setitem(sys.modules, "orbax", pkg)
+    monkeypatch.setitem(sys.modules, "orbax.checkpoint", stub)
+    (tmp_path / "jax" / "params").mkdir(parents=True)
+    (tmp_path / "jax" / "assets" / "robot").mkdir(parents=True)
+    (tmp_path / "jax" / "assets" / "robot" / "norm_stats.json").write_text("{}")
+    tree = convert.restore_params(tmp_path / "jax" / "params")
+    assert isinstance(tree["PaliGemma"]["llm"]["embedder"]["input_embedding"], np.ndarray)  # "value" level removed
+    out = convert.convert_checkpoint(tmp_path / "jax", tmp_path / "torch", config=pcfg)
+    assert sorted(p.name for p in (tmp_path / "torch").iterdir()) == ["assets", "model.safetensors"]
+    from kai0_amd.checkpoint import load_model_safetensors
+
+    m2 = PI0Pytorch(pcfg)
+    load_model_safetensors(m2, out + "/model.safetensors")
+    dead = "paligemma_with_expert.gemma_expert.lm_head.weight"
+    for (k, a), (_, b) in zip(src_model.state_dict().items(), m2.state_dict().items()):
+        assert a.dtype == b.dtype, k
+        if k != dead:  # the JAX tree has no entry for the dead expert lm_head: zero-filled
+            assert torch.equal(a, b), k
+    monkeypatch.delitem(sys.modules, "orbax.checkpoint")
+    monkeypatch.delitem(sys.modules, "orbax")
+    with pytest.raises(ImportError, match="orbax-checkpoint"):
+        convert.restore_params(tmp_path / "jax" / "params")

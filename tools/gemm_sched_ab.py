@@ -43,13 +43,32 @@ cases = [
     ("B=1 gate NT 968x16384x2048", 968, 16384, 2048, 0),
     ("square 8192              ", 8192, 8192, 8192, 0),
 ]
+if os.environ.get("AB_LAYOUT", "NT") != "NT":
+    lay = os.environ["AB_LAYOUT"]
+    cases = [(f"{lay} wgrad gate 16384x2048x30976", 16384, 2048, 30976, 0), (f"{lay} wgrad down 2048x16384x30976", 2048, 16384, 30976, 0),
+             (f"{lay} wgrad qkv 2560x2048x30976   ", 2560, 2048, 30976, 0), (f"{lay} siglip fc1 4304x1152x24576 ", 4304, 1152, 24576, 0),
+             (f"{lay} siglip qkv 3456x1152x24576 ", 3456, 1152, 24576, 0), (f"{lay} ragged 1000x520x4104       ", 1000, 520, 4104, 0),
+             (f"{lay} square 8192               ", 8192, 8192, 8192, 0)]  # fmt: skip
 out = []
 for name, M, N, K, act in cases:
-    x = torch.randn(M, K, device=dev).to(BF16)
-    w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+    lay = os.environ.get("AB_LAYOUT", "NT")
+    if lay == "NT":
+        x = torch.randn(M, K, device=dev).to(BF16)
+        w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+        lkw = dict(lda=K, ldb=K)
+    elif lay == "TN":
+        x = torch.randn(K, M, device=dev).to(BF16)
+        w = (torch.randn(K, N, device=dev) * 0.05).to(BF16)
+        lkw = dict(a_kc=False, b_kc=False, lda=M, ldb=N)
+    else:  # NN
+        x = torch.randn(M, K, device=dev).to(BF16)
+        w = (torch.randn(K, N, device=dev) * 0.05).to(BF16)
+        lkw = dict(a_kc=True, b_kc=False, lda=K, ldb=N)
     ldc = (N + 63) // 64 * 64
     res = {c: torch.empty(M, ldc, dtype=BF16, device=dev) for c in CFGS}
-    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc)
+    kw = dict(M=M, N=N, K=K, ldc=ldc, **lkw)
+    if lay == "TN" and K >= 8192:
+        kw["split_k"] = ops.pick_split_k_wgrad(M, N, K)
     extra = {}
     if act:
         g = torch.randn(M, ldc, device=dev).to(BF16)
@@ -84,4 +103,4 @@ for name, M, N, K, act in cases:
     del x, w, res
 set_cfg(0)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/gemm_sched_ab.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/gemm_sched_ab_{os.environ.get('AB_LAYOUT', 'NT')}.json", "w"), indent=1)
