@@ -195,6 +195,15 @@ int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void* O, cons
                      int batch, int rows, int H, int HD, int Sk, int q0, int64_t q_bs, int64_t k_bs, int64_t k_ld,
                      int k_rows, int64_t vt_bs, int64_t vt_ld, int64_t qcode_ld, int64_t kcode_ld, float scale,
                      void* workspace, int64_t workspace_bytes, kai0_stream_t stream);
+/* Query side of the backward of the masked MQA attention with stored probabilities (modeling_gemma.py:230-253 through
+ * autograd), one launch per call:
+ *   D = rowsum(dO * O);  dP = dO V^T (f32, never written);  dS = bf16((P * (dP - D)) * scale);  dQ = bf16(dS K)
+ * dO, O, dQ: bf16 rows of HD elements (row stride ldo; the H query heads of a position folded into the rows, as kai0_attn_fwd
+ * takes Q); P, dS: bf16 [batch][rows][ldp] (the forward's probabilities in, dS out: dK = dS^T Q and dV = P^T dO stay GEMMs);
+ * K, V: bf16 [batch][Sk][ld]; batch strides sO / sK / sV / sP in elements.  HD % 8 == 0, HD <= 256. */
+int kai0_attn_bwd_dq(const void* dO, const void* O, const void* P, const void* K, const void* V, void* dS, void* dQ, int batch,
+                     int rows, int Sk, int HD, int64_t ldo, int64_t ldk, int64_t ldv, int64_t ldp, int64_t sO, int64_t sK,
+                     int64_t sV, int64_t sP, float scale, kai0_stream_t stream);
 /* bytes of the bf16 logits scratch kai0_attn_decode needs */
 int64_t kai0_attn_decode_workspace_bytes(int batch, int rows);
 /* batched strided transpose: dst[z][c][r] = src[z][r][c], r < R, c < C (all extents / strides multiples of 8) */

@@ -94,6 +94,8 @@ _PROTOS: dict[str, list] = {
     "kai0_skinny_desc_size": [],
     "kai0_attn_decode": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i64, c_i64,
                          c_i64, c_i64, c_f, c_p, c_i64, c_p],
+    "kai0_attn_bwd_dq": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                         c_f, c_p],
     "kai0_transpose_strided_bf16": [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
     "kai0_rope_table": [c_p, c_p, c_p, c_p, c_i64, c_i, c_p],
     "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i64, c_p],

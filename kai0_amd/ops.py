@@ -236,6 +236,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+_SPLIT_RULE = os.environ.get("KAI0_SPLIT_RULE", "new")
+
+
 def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
     """Split-K factor for a GEMM with few 128x128 output tiles: spread the contraction over the chip's ~512 block slots
     (256 CUs x 2 blocks) without making a chunk shorter than 4 K-tiles.  Covers both the long-contraction wgrads
@@ -245,7 +248,12 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
         return 1
     if M <= 128:  # one row of tiles: pure weight streaming, latency-bound -> chunks as short as 2 K-tiles
         return max(1, min(32, 768 // tiles, K // 128))
-    return max(1, min(16, 768 // tiles, K // 256))
+    if _SPLIT_RULE == "old":
+        return max(1, min(16, 768 // tiles, K // 256))
+    # a few hundred to a few thousand rows (the action expert at B = 32, the B = 1 prefix pass): measured on MI355X
+    # (tools/expert_gemm_probe.py, us per call over split 1..8): ~400 blocks of 128x128 in total with chunks of >= 768 is the
+    # optimum; the former rule (up to 768 blocks, chunks down to 256) cost 20-60 % on these shapes
+    return max(1, min(round(400 / tiles), K // 768))
 
 
 # Split-K of the weight-gradient GEMMs (TN, contraction = B*S rows) whose output has few 256x256 tiles, measured on MI355X
@@ -1136,6 +1144,7 @@ def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H
 
 
 _ATTN_BWD_NT = os.environ.get("KAI0_ATTN_BWD_NT", "1") != "0"
+_ATTN_BWD_FUSED = os.environ.get("KAI0_ATTN_BWD", "fused") != "gemm"
 _ATTN_BWD_SPLIT = os.environ.get("KAI0_ATTN_BWD_SPLIT", "auto")
 
 
@@ -1217,13 +1226,21 @@ class JointAttentionFn(torch.autograd.Function):
         # dS[b] [M, S_ld] = softmax'(dP), dP[b] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K]): the softmax
         # backward runs in the GEMM epilogue on the f32 accumulator (dP is never rounded or written; the row term
         # <dP, P> is computed as rowsum(dO * O), kai0hip.h act 4)
-        dsum = rowdot(datt, att, HD)  # [Bn * S_ld * H]
         dscores = torch.empty_like(probs)
-        gemm(datt, v_all, dscores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
-             sB=(S_ld * HD, 0), sC=(M * S_ld, 0), act=4, aux1=probs, rowvec=dsum, rv=(S_ld * H, 0, 1), scale=scale)  # fmt: skip
-        # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
         dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-        if _ATTN_BWD_NT and S_ld % 8 == 0:
+        if _ATTN_BWD_FUSED:
+            # one launch: D = rowsum(dO * O), dP = dO V^T in f32, dS written once, dQ = dS K accumulated on chip
+            _lib.call("kai0_attn_bwd_dq", datt.data_ptr(), att.data_ptr(), probs.data_ptr(), k_all.data_ptr(), v_all.data_ptr(),
+                      dscores.data_ptr(), dq_all.data_ptr(), Bn, M, S, HD, HD, HD, HD, S_ld, S_ld * H * HD, S_ld * HD, S_ld * HD,
+                      M * S_ld, scale, _stream())  # fmt: skip
+        else:
+            dsum = rowdot(datt, att, HD)  # [Bn * S_ld * H]
+            gemm(datt, v_all, dscores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
+                 sB=(S_ld * HD, 0), sC=(M * S_ld, 0), act=4, aux1=probs, rowvec=dsum, rv=(S_ld * H, 0, 1), scale=scale)  # fmt: skip
+        # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
+        if _ATTN_BWD_FUSED:
+            pass
+        elif _ATTN_BWD_NT and S_ld % 8 == 0:
             # through K^T (0.5 MB per sample to transpose): both operands contraction-contiguous -> the NT quadrant schedule
             kt = torch.empty((Bn, HD, S_ld), dtype=BF16, device=dev)
             transpose_strided(k_all, kt, R=S_ld, C=HD, src_ld=HD, dst_ld=S_ld, batch=Bn, src_bs=S_ld * HD, dst_bs=HD * S_ld)
