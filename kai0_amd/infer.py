@@ -27,6 +27,9 @@ from . import _lib, ops
 from .ops import BF16, F32, gemm, pick_split_k, round_up
 
 logger = logging.getLogger("kai0_amd")
+# split-K of the prefix pass's q|k|v, o_proj and down_proj GEMMs ("q,o,d"; 0 = ops.pick_split_k).  Swept on MI355X at B = 1
+# (tools/prefix_splits.sh): 1,1,6 -> prefix pass 6.52 ms; the automatic rule 6.80; everything else within 0.1-0.25 ms
+_PREFIX_SPLITS = [int(x) for x in os.environ.get("KAI0_PREFIX_SPLITS", "1,1,6").split(",")]
 
 
 def NQ_ok(nq: int) -> bool:
@@ -239,7 +242,7 @@ class InferenceEngine:
         out = torch.empty((M, N), dtype=BF16, device=self.dev)
         gemm(self.att_buf, lin.weight, out, M=M, N=N, K=H * HD, lda=H * HD, ldb=H * HD, ldc=N,
              a_map=(rows_pb, self.S_ld, row0), residual=residual, ldr=N, gate=gate, gate_rpb=rows_pb, gate_ld=N,
-             split_k=pick_split_k(M, N, H * HD))  # fmt: skip
+             split_k=(_PREFIX_SPLITS[1] if M > 128 else 0) or pick_split_k(M, N, H * HD))  # fmt: skip
         return out
 
     # ------------------------------------------------------------------------------------------------ passes
@@ -276,7 +279,8 @@ class InferenceEngine:
                 break
             # stacked q|k|v projection written straight into the padded q buffer and the K / V caches
             gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
-                 c_map=(P, S_ld, 0), segs=[(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)])  # fmt: skip
+                 c_map=(P, S_ld, 0), segs=[(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)],
+                 split_k=_PREFIX_SPLITS[0] or 1)  # fmt: skip
             ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
             ops.rope_(self.q_buf, self.pos_prefix, inv_freq, B, P, S_ld, 0, H, HD)
             self._attend(l, 0, P, P, qcode, kcode)
@@ -284,7 +288,8 @@ class InferenceEngine:
             hp = ops.rmsnorm(xp, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
             g = self._lin(hp, layer.mlp.gate_proj.weight)
             hmid = self._lin(hp, layer.mlp.up_proj.weight, act=2, aux1=g)  # GeGLU in the epilogue
-            xp = ops.linear_fwd(hmid, layer.mlp.down_proj.weight, residual=xp)
+            xp = self._lin(hmid, layer.mlp.down_proj.weight, residual=xp,
+                           split=_PREFIX_SPLITS[2] or pick_split_k(M, self.Dp, hmid.shape[1]))
 
     def _modulations(self, times: list[float]):
         """time embedding -> time MLP -> adaRMS `dense` for every layer and step at once (rows = step*B + b): one f32 GEMM over
