@@ -337,6 +337,12 @@ def main():
     timer = None
     timer_steps = 2
     if not args.no_gemm_timing:
+        from kai0_amd import model as _model
+
+        # every launch is timed ALONE: in the timed region above the action expert's chain (a few dozen small launches per
+        # layer) runs on a second stream next to the PaliGemma tower's GEMMs (model.forward_joint), and two kernels that share
+        # the chip would each be charged the other's time
+        dual_was = _model.set_expert_stream(False)
         if rank == 0:
             timer = GemmTimer()
             timer.install()
@@ -345,6 +351,7 @@ def main():
         barrier()
         if timer is not None:
             timer.uninstall()
+        _model.set_expert_stream(dual_was)
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -410,7 +417,8 @@ def main():
                 "gemm_ms_per_step": gemm_ms / timer_steps,
                 "algorithmic_tflop_per_step": TRAIN_TFLOP_PER_SAMPLE * B,
                 "gemm_tflop_per_step": gemm_flops / timer_steps / 1e12,
-                "timed": f"HIP events over {timer_steps} further identical steps right after the timed region",
+                "timed": f"HIP events over {timer_steps} further identical steps right after the timed region, with the second "
+                         "(action-expert) stream off so that every launch owns the chip while it is timed",
                 "step_frac_of_mfma_peak": TRAIN_TFLOP_PER_SAMPLE * B / (ms_per_step / 1e3) / MFMA_BF16_PEAK_TFLOPS,
             }
             if os.environ.get("KAI0_GEMM_BREAKDOWN"):

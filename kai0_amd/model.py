@@ -18,6 +18,9 @@ Layout choices (MI355X-first, not a translation of the HF modules):
 
 from __future__ import annotations
 
+import contextlib
+import os
+
 import logging
 import math
 
@@ -259,6 +262,16 @@ def build_mask_codes(pad_masks: torch.Tensor, att_masks: torch.Tensor):
     return qcode, kcode, pos
 
 
+_EXPERT_STREAM = os.environ.get("KAI0_EXPERT_STREAM", "1") != "0"  # the action expert's chain on a second HIP stream
+
+
+def set_expert_stream(on: bool) -> bool:
+    """Switch the second stream of `forward_joint` on / off (bench.py times every GEMM launch alone); returns the old setting."""
+    global _EXPERT_STREAM
+    old, _EXPERT_STREAM = _EXPERT_STREAM, bool(on)
+    return old
+
+
 class _NoUnitHooks:
     """Default `unit_hooks`: the model announces each sharding unit (kai0_amd.sharded) to nobody."""
 
@@ -357,33 +370,68 @@ class PaliGemmaWithExpertModel(nn.Module):
         H, HD = cfg.num_heads, cfg.head_dim
         inv_freq = lm.rope_inv_freq()
 
+        # The two towers meet only in the joint attention.  The action expert's side of a layer is ~15 launches over B*50 rows
+        # (10-25 us each: pure launch latency, a few dozen tiles), the PaliGemma side a handful of GEMMs over B*968 rows
+        # (0.2-2.3 ms each): the expert's chain runs on a second HIP stream next to them, joined before and forked after the
+        # attention.  autograd replays every backward node on the stream its forward ran on (with the event hand-offs and
+        # allocator bookkeeping between them), so the backward overlaps the same way.  Not with rematerialisation (the
+        # recomputation would run inside another node's backward).
+        dual = (_EXPERT_STREAM and prefix.is_cuda and not (self.remat and self.training)
+                and getattr(self.unit_hooks, "mode", "zero2") != "fsdp")  # fsdp frees a unit's parameters behind the main stream only
+        main = torch.cuda.current_stream() if dual else None
+        side = ops.side_stream(prefix.device) if dual else None
+
+        def on_side():
+            return torch.cuda.stream(side) if dual else contextlib.nullcontext()
+
+        def hand(ts, to):  # tensors allocated under one stream and read under the other
+            if dual:
+                for t in ts:
+                    t.record_stream(to)
+
         def layer_fn(xp, xs, lp, le):
-            xp, hp = ops.rmsnorm_res(xp, lp.input_layernorm.weight, lp.input_layernorm.eps)
-            mod1 = ops.linear_f32(cond, le.input_layernorm.dense.weight, le.input_layernorm.dense.bias)
-            xs, hs, gate1 = ops.adarms_res(xs, mod1, Hs, le.input_layernorm.eps)
             ap, ae = lp.self_attn, le.self_attn
-            qkv = (*ops.linear_multi(hp, [ap.q_proj.weight, ap.k_proj.weight, ap.v_proj.weight]),
-                   *ops.linear_multi(hs, [ae.q_proj.weight, ae.k_proj.weight, ae.v_proj.weight]))  # fmt: skip
-            att_p, att_s = ops.joint_attention(pos, qcode, kcode, inv_freq, H, HD, (P, Hs), qkv)
+            with on_side():
+                mod1 = ops.linear_f32(cond, le.input_layernorm.dense.weight, le.input_layernorm.dense.bias)
+                xs, hs, gate1 = ops.adarms_res(xs, mod1, Hs, le.input_layernorm.eps)
+                qkv_s = ops.linear_multi(hs, [ae.q_proj.weight, ae.k_proj.weight, ae.v_proj.weight])
+            xp, hp = ops.rmsnorm_res(xp, lp.input_layernorm.weight, lp.input_layernorm.eps)
+            qkv_p = ops.linear_multi(hp, [ap.q_proj.weight, ap.k_proj.weight, ap.v_proj.weight])
+            if dual:
+                main.wait_stream(side)
+                hand(qkv_s, main)
+            att_p, att_s = ops.joint_attention(pos, qcode, kcode, inv_freq, H, HD, (P, Hs), (*qkv_p, *qkv_s))
+            if dual:
+                side.wait_stream(main)
+                hand((att_s,), side)
+            # suffix (action expert): gated residuals (modeling_gemma.py:209-227)
+            with on_side():
+                xs = ops.gated_residual(xs, _lin(att_s, ae.o_proj), gate1, Hs)
+                mod2 = ops.linear_f32(cond, le.post_attention_layernorm.dense.weight, le.post_attention_layernorm.dense.bias)
+                xs, hs, gate2 = ops.adarms_res(xs, mod2, Hs, le.post_attention_layernorm.eps)
+                ys = ops.geglu_mlp(hs, le.mlp.gate_proj.weight, le.mlp.up_proj.weight, le.mlp.down_proj.weight)
+                xs = ops.gated_residual(xs, ys, gate2, Hs)
             # prefix: o_proj + residual fused in the GEMM epilogue, then RMSNorm -> GeGLU MLP -> residual
             xp = _lin(att_p, ap.o_proj, residual=xp)
             xp, hp = ops.rmsnorm_res(xp, lp.post_attention_layernorm.weight, lp.post_attention_layernorm.eps)
             xp = ops.geglu_mlp(hp, lp.mlp.gate_proj.weight, lp.mlp.up_proj.weight, lp.mlp.down_proj.weight, residual=xp)
-            # suffix (action expert): gated residuals (modeling_gemma.py:209-227)
-            xs = ops.gated_residual(xs, _lin(att_s, ae.o_proj), gate1, Hs)
-            mod2 = ops.linear_f32(cond, le.post_attention_layernorm.dense.weight, le.post_attention_layernorm.dense.bias)
-            xs, hs, gate2 = ops.adarms_res(xs, mod2, Hs, le.post_attention_layernorm.eps)
-            ys = ops.geglu_mlp(hs, le.mlp.gate_proj.weight, le.mlp.up_proj.weight, le.mlp.down_proj.weight)
-            xs = ops.gated_residual(xs, ys, gate2, Hs)
             return xp, xs
 
         xp, xs = prefix, suffix
         hk = self.unit_hooks
+        if dual:
+            side.wait_stream(main)
+            hand((xs, cond), side)
         for l, (lp, le) in enumerate(zip(lm.layers, ex.layers, strict=True)):
             hk.pre_forward(f"joint.{l}")
+            if dual:
+                side.wait_stream(main)  # the unit's parameters may have just been completed on the main stream
             xp, xs = self._maybe_remat(layer_fn, xp, xs, lp, le)
             xp, xs = hk.post_forward(f"joint.{l}", xp, xs)
         hk.pre_forward("head")  # final adaRMS norm, action_out_proj (and the estimator's value head): never released early
+        if dual:
+            main.wait_stream(side)
+            hand((xs,), main)
         modf = ops.linear_f32(cond, ex.norm.dense.weight, ex.norm.dense.bias)
         out, _ = ops.adarms(xs, modf, Hs, ex.norm.eps)
         return out

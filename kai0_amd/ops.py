@@ -313,9 +313,65 @@ def _grad_ret(param, g):
         return g
     dst = getattr(param, "_kai0_grad_out", None)
     if dst is not None and g.data_ptr() == dst.data_ptr():
+        if _DUAL:
+            _note_side_gradient(param)
         param._kai0_grad_done()
         return None
     return g
+
+
+# ------------------------------------------------------------------------------------------ second HIP stream
+# model.forward_joint runs the action expert's chain on a second stream (and autograd its backward): (main, side) per device.
+_DUAL: dict = {}
+_JOIN_PENDING: dict = {}
+
+
+def side_stream(device):
+    """The second stream of `device`, paired with the CURRENT stream as its main one."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    main = torch.cuda.current_stream(idx)
+    pair = _DUAL.get(idx)
+    if pair is None or pair[0] != main:
+        pair = _DUAL[idx] = (main, pair[1] if pair is not None else torch.cuda.Stream(device=idx))
+    return pair[1]
+
+
+def stream_pair(device):
+    """(main, side) if the second stream has been used on `device`, else None."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _DUAL.get(idx)
+
+
+def join_streams(device) -> None:
+    """The current stream waits for both streams of the pair (end of a backward pass, before the optimizer / a collective)."""
+    pair = stream_pair(device)
+    if pair is None:
+        return
+    cur = torch.cuda.current_stream(pair[0].device_index)
+    for st in pair:
+        if st != cur:
+            cur.wait_stream(st)
+
+
+def _note_side_gradient(param) -> None:
+    """A gradient was just written in place (into the trainer's flat buffer) by a backward node running on the second stream:
+    have the main stream pick it up when this backward pass ends (autograd itself only synchronises gradients it accumulates)."""
+    pair = stream_pair(param.device)
+    if pair is None or torch.cuda.current_stream(pair[0].device_index) != pair[1]:
+        return
+    idx = pair[0].device_index
+    if _JOIN_PENDING.get(idx):
+        return
+
+    def join():
+        _JOIN_PENDING[idx] = False
+        pair[0].wait_stream(pair[1])
+
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        _JOIN_PENDING[idx] = True
+    except RuntimeError:  # not inside a backward pass
+        pair[0].wait_stream(pair[1])
 
 
 # ----------------------------------------------------------------------------------------- autograd shims

@@ -224,7 +224,14 @@ class ShardedDataParallel:
         """SUM of the ranks' gradients (the loss carries the 1/N), each rank keeping its 1/N slice."""
         if not self.collectives:
             return None  # grad_shard aliases flat_grad
+        self._join_streams()  # the bucket's gradients were written under two streams (ops.side_stream): behind both
         return dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _join_streams(self):
+        if self.device.type == "cuda":
+            from . import ops
+
+            ops.join_streams(self.device)
 
     def _all_gather(self, b: _Bucket):
         if not self.collectives:
@@ -368,6 +375,7 @@ class ShardedDataParallel:
         device tensor."""
         self.step_count += 1
         self._check_views()
+        self._join_streams()  # gradients written by backward nodes on the second stream
         for b in self.buckets:
             if b.pending > 0:  # parameters that received no gradient this step contribute zeros
                 for p, o in zip(b.params, b.offsets):
