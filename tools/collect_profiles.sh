@@ -4,6 +4,9 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/summary; rm -rf $OUT; mkdir -p $OUT
+# per-kernel durations are taken with the action expert's second stream off (KAI0_EXPERT_STREAM=0): every kernel then owns the
+# chip while it runs, which is also how bench.py times the GEMM launches for its roofline object
+export KAI0_EXPERT_STREAM=0
 BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency"
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -o train -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 python tools/prof_summary.py $(find /tmp/prof_train -name "*.db" | head -1) > $OUT/train_kernel_stats.md 2>&1

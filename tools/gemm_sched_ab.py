@@ -60,6 +60,10 @@ for name, M, N, K, act in cases:
         x = torch.randn(K, M, device=dev).to(BF16)
         w = (torch.randn(K, N, device=dev) * 0.05).to(BF16)
         lkw = dict(a_kc=False, b_kc=False, lda=M, ldb=N)
+    elif lay == "AT":  # A contraction-strided [K][M], B K-contiguous [N][K] (a weight gradient with its small operand transposed)
+        x = torch.randn(K, M, device=dev).to(BF16)
+        w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+        lkw = dict(a_kc=False, b_kc=True, lda=M, ldb=K)
     else:  # NN
         x = torch.randn(M, K, device=dev).to(BF16)
         w = (torch.randn(K, N, device=dev) * 0.05).to(BF16)
@@ -67,7 +71,7 @@ for name, M, N, K, act in cases:
     ldc = (N + 63) // 64 * 64
     res = {c: torch.empty(M, ldc, dtype=BF16, device=dev) for c in CFGS}
     kw = dict(M=M, N=N, K=K, ldc=ldc, **lkw)
-    if lay == "TN" and K >= 8192:
+    if lay in ("TN", "AT", "NN") and K >= 8192:
         kw["split_k"] = ops.pick_split_k_wgrad(M, N, K)
     extra = {}
     if act:
