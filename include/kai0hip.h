@@ -166,7 +166,12 @@ typedef struct kai0_skinny_desc {
     int64_t ldr;
     const float* rope_cos;
     const float* rope_sin;
-    int32_t rope_half, _pad;
+    int32_t rope_half;
+    /* 1 (split_k == -1 only): W is stored MFMA-fragment-major — for the 16-row tile t of output columns and the 32-wide step s
+     * of the contraction one contiguous 1-KiB block at element offset (t * (K / 32) + s) * 512, holding W[16 t + i][32 s + 8 g + e] at
+     * (i + 16 g) * 8 + e (i < 16, g < 4, e < 8) — so that every wave-instruction of the weight stream is one contiguous KiB
+     * (what kai0_amd.ops.pack_skinny_weight produces; ldw is ignored). */
+    int32_t w_packed;
     void* workspace;
     int64_t workspace_bytes;
     /* split_k == -1: the whole contraction inside one block (K / 256 waves, K in {1024, 2048, 4096}): no partial products, the

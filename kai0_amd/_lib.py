@@ -76,7 +76,7 @@ class SkinnyDesc(C.Structure):
         ("a_bs", c_i64), ("a_off", c_i64), ("c_bs", c_i64), ("c_off", c_i64),
         ("seg", SkinnySeg * 3), ("nseg", C.c_int32), ("gate_rpb", C.c_int32),
         ("gate", c_p), ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64),
-        ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("_pad", C.c_int32),
+        ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("w_packed", C.c_int32),
         ("workspace", c_p), ("workspace_bytes", c_i64),
         ("mod", c_p), ("mod_ld", c_i64), ("mod_rpb", C.c_int32), ("eps", c_f),
     ]  # fmt: skip

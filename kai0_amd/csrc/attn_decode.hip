@@ -40,14 +40,48 @@ constexpr int DEC_KEYS = 1024;  // padded key range (32 groups of 32)
 constexpr int DEC_KSPLIT = 4;   // logits kernel: key ranges per query tile (8 groups = 256 keys each, 2 groups per wave)
 constexpr int DEC_HSPLIT = 4;   // P V kernel: head-dim ranges per query tile (64 each)
 
+// Staging of a wave's operand rows through wave-private LDS.  The key / value caches are read by every query tile of a launch,
+// i.e. out of L2, and the direct MFMA-fragment pattern (16 rows x 64 B per wave-instruction) gets 31-34 GB/s per CU there
+// against 80-90 GB/s for contiguous 1-KiB runs (tools/probes/frag_load.hip).  Each wave therefore reads its rows as whole
+// 512-B runs (two per instruction), parks them in its own LDS region (row stride 528 B) and takes its fragments from there
+// with ds_read_b128; no block barrier is involved.
+constexpr int DEC_ROWB = 512 + 16;            // LDS bytes per staged row (256 bf16 + 16 B: consecutive rows on distinct banks)
+constexpr int DEC_STAGE = 64 * DEC_ROWB;      // one wave's 64 rows
+
+__device__ __forceinline__ void dec_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- kernel 1: masked, scaled, bf16-rounded logits L[b][row][key] (-inf where hidden) ----------------------------
 __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t* __restrict__ L, int64_t l_bs) {
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, r0 = blockIdx.x * 16;
     const int rq = r0 + i;
     const bool qok = rq < p.rows;
+    char* my = dec_smem + wave * DEC_STAGE;
+    // this wave's 64 keys (two 32-key groups) as 32 contiguous 1-KiB reads: instruction q covers key rows 2q, 2q + 1.  Rows 16-31
+    // of each 32-row group are stored with their 16-B column index xor 4: the fragment reads below touch rows {0-3, 8-11, 16-19,
+    // 24-27} of a group per 16 lanes, and with a 528-B row stride rows r and r + 16 would share their banks.
+    const int key0 = (blockIdx.y * 8 + wave * 2) * 32;
+    const bf16_t* Kb = p.K + (int64_t)b * p.k_bs;
+    {
+        const int sub = lane >> 5, c16 = lane & 31;
+        bf16x8 ch[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int row = 2 * q + sub;
+            ch[q] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)min(key0 + row, p.k_rows - 1) * p.k_ld + c16 * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int row = 2 * q + sub;
+            *reinterpret_cast<bf16x8*>(my + row * DEC_ROWB + ((c16 ^ ((row & 16) >> 2)) << 4)) = ch[q];
+        }
+    }
     const bf16_t* Qb = p.Q + (int64_t)b * p.q_bs + ((int64_t)p.q0 * p.H + (qok ? rq : 0)) * DEC_HD + 8 * g;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 qf[8];
@@ -55,21 +89,11 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
     for (int c = 0; c < 8; ++c) qf[c] = qok ? *reinterpret_cast<const bf16x8*>(Qb + 32 * c) : zero8;
     // qc: INT_MIN hides everything (row outside the problem); without codes every real key is visible
     const int qc = qok ? (p.qcode ? p.qcode[(int64_t)b * p.qc_ld + p.q0 + rq / p.H] : INT_MAX - 1) : INT_MIN;
-    const bf16_t* Kb = p.K + (int64_t)b * p.k_bs + 8 * g;
     const int arow = 8 * (i >> 2) + (i & 3);  // key (within the group) fed to A-row i of tile 0; tile 1: + 4
-    bf16x8 kf[2][2][8];
     int kc[2][8];
 #pragma unroll
     for (int gl = 0; gl < 2; ++gl) {
-        const int base = (blockIdx.y * 8 + wave * 2 + gl) * 32;
-        const int k0r = min(base + arow, p.k_rows - 1), k1r = min(base + arow + 4, p.k_rows - 1);
-        const bf16_t* k0p = Kb + (int64_t)k0r * p.k_ld;
-        const bf16_t* k1p = Kb + (int64_t)k1r * p.k_ld;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            kf[gl][0][c] = *reinterpret_cast<const bf16x8*>(k0p + 32 * c);
-            kf[gl][1][c] = *reinterpret_cast<const bf16x8*>(k1p + 32 * c);
-        }
+        const int base = key0 + gl * 32;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {  // unconditional (clamped) loads: all in flight together
             const int key = base + 8 * g + e;
@@ -77,14 +101,21 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
             kc[gl][e] = key < p.Sk ? code : INT_MAX;
         }
     }
+    dec_wave_sync();
 #pragma unroll
     for (int gl = 0; gl < 2; ++gl) {
-        const int base = (blockIdx.y * 8 + wave * 2 + gl) * 32;
+        const int base = key0 + gl * 32;
+        const int ra = gl * 32 + arow, rb = ra + 4;
+        const char* pa = my + ra * DEC_ROWB;
+        const char* pb = my + rb * DEC_ROWB;
+        const int xa = (ra & 16) >> 2, xb = (rb & 16) >> 2;
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[gl][0][c], qf[c], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[gl][1][c], qf[c], a1, 0, 0, 0);
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(pa + (((4 * c + g) ^ xa) << 4));
+            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(pb + (((4 * c + g) ^ xb) << 4));
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[c], a1, 0, 0, 0);
         }
         // lane (q = i, g) holds keys base + 8g + e: e < 4 in a0, e >= 4 in a1
         bf16x8 o;
@@ -99,26 +130,32 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
 
 // ---- kernel 2: f32 softmax of the stored logits, P bf16, O = P V for a 64-wide slice of the head dim ------------------
 __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16_t* __restrict__ L, int64_t l_bs) {
-    __shared__ float red[4][16][64 + 4];
-    __shared__ float sstat[2][4][16];
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+    float (*red)[16][64 + 4] = reinterpret_cast<float (*)[16][64 + 4]>(dec_smem + 4 * DEC_STAGE);
+    float (*sstat)[4][16] = reinterpret_cast<float (*)[4][16]>(dec_smem + 4 * DEC_STAGE + sizeof(float) * 4 * 16 * 68);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, r0 = blockIdx.x * 16, h0 = blockIdx.y * 64;
     const int ngroups = (p.Sk + 31) >> 5;
-    // logits of row r0 + i: wave w owns key groups w, w + 4, ... (8 groups), lane (q, g) keys 8g..8g+7 of each
-    const bf16_t* Lr = L + (int64_t)b * l_bs + (int64_t)(r0 + i) * DEC_KEYS + 8 * g;
+    // wave w owns the 256 keys [256 w, 256 w + 256) = key groups 8 w .. 8 w + 7; lane (q, g) keys 8g..8g+7 of each group
+    // logits of row r0 + i
+    const bf16_t* Lr = L + (int64_t)b * l_bs + (int64_t)(r0 + i) * DEC_KEYS + wave * 256 + 8 * g;
     bf16x8 lf[8];
 #pragma unroll
-    for (int gl = 0; gl < 8; ++gl) lf[gl] = *reinterpret_cast<const bf16x8*>(Lr + (wave + 4 * gl) * 32);
-    // value fragments (A operand): rows h0 + 16t + i of Vt, keys of the same groups — in flight during the statistics
-    const bf16_t* Vb = p.Vt + (int64_t)b * p.vt_bs + (int64_t)(h0 + i) * p.vt_ld + 8 * g;
-    bf16x8 vf[8][4];
+    for (int gl = 0; gl < 8; ++gl) lf[gl] = *reinterpret_cast<const bf16x8*>(Lr + gl * 32);
+    // value rows h0 .. h0 + 63 of Vt, this wave's 256 keys: 64 runs of 512 B, two per instruction, parked in the wave's LDS
+    // region (see dec_logits_kernel) — in flight during the statistics
+    char* my = dec_smem + wave * DEC_STAGE;
+    {
+        const int sub = lane >> 5, c16 = lane & 31;
+        const int kcol = min(wave * 256 + c16 * 8, (int)p.vt_ld - 8);  // (keys past the padded row end: never multiplied, P = 0)
+        const bf16_t* Vb = p.Vt + (int64_t)b * p.vt_bs + (int64_t)h0 * p.vt_ld + kcol;
+        bf16x8 ch[32];
 #pragma unroll
-    for (int gl = 0; gl < 8; ++gl) {
-        const int gi = min(wave + 4 * gl, ngroups - 1);
+        for (int q = 0; q < 32; ++q) ch[q] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)(2 * q + sub) * p.vt_ld);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vf[gl][t] = *reinterpret_cast<const bf16x8*>(Vb + gi * 32 + (int64_t)(16 * t) * p.vt_ld);
+        for (int q = 0; q < 32; ++q) *reinterpret_cast<bf16x8*>(my + (2 * q + sub) * DEC_ROWB + (c16 << 4)) = ch[q];
     }
     float s[8][8];
     float m = -INFINITY;
@@ -147,7 +184,7 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     if (g == 0) sstat[1][wave][i] = sum;
-    __syncthreads();
+    __syncthreads();  // (also: every lane's staged value rows are in LDS — the ds_writes above were waited for by the barrier's lgkmcnt)
     sum = (sstat[1][0][i] + sstat[1][1][i]) + (sstat[1][2][i] + sstat[1][3][i]);
     const float inv = (m > -INFINITY && sum > 0.f) ? 1.0f / sum : 0.f;
     f32x4 acc[4];
@@ -155,12 +192,15 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int gl = 0; gl < 8; ++gl) {
-        const bool live = wave + 4 * gl < ngroups;
+        const bool live = wave * 8 + gl < ngroups;
         bf16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = f2bf((live && m > -INFINITY) ? s[gl][e] * inv : 0.f);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[gl][t], pf, acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(my + (16 * t + i) * DEC_ROWB + ((4 * gl + g) << 4));
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[t], 0, 0, 0);
+        }
     }
     // acc[t]: lane (q = i, g) holds hd = h0 + 16t + 4g + reg
 #pragma unroll
@@ -176,6 +216,9 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
         *reinterpret_cast<bf16x4*>(op) = o;
     }
 }
+
+constexpr int DEC_LOGITS_LDS = 4 * DEC_STAGE;
+constexpr int DEC_PV_LDS = 4 * DEC_STAGE + (int)sizeof(float) * (4 * 16 * 68 + 2 * 4 * 16);
 
 }  // namespace
 
@@ -202,9 +245,16 @@ KAI0_API int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void
               q_bs, k_bs, k_ld, vt_bs, vt_ld, qcode_ld, kcode_ld, scale};
     const int qt = (rows + 15) / 16;
     const int64_t l_bs = (int64_t)qt * 16 * DEC_KEYS;
-    hipLaunchKernelGGL(dec_logits_kernel, dim3(qt, DEC_KSPLIT, batch), dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)workspace,
-                       l_bs);
-    hipLaunchKernelGGL(dec_pv_kernel, dim3(qt, DEC_HSPLIT, batch), dim3(256), 0, (hipStream_t)stream, p,
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dec_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LOGITS_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_PV_LDS);
+        KAI0_REQUIRE(e == hipSuccess, "kai0_attn_decode: cannot reserve %d B of LDS: %s", DEC_PV_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dec_logits_kernel, dim3(qt, DEC_KSPLIT, batch), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
+                       (bf16_t*)workspace, l_bs);
+    hipLaunchKernelGGL(dec_pv_kernel, dim3(qt, DEC_HSPLIT, batch), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
                        (const bf16_t*)workspace, l_bs);
     return kai0_check_launch("kai0_attn_decode");
 }

@@ -63,6 +63,7 @@ struct SkinnyArgs {
     int mod_rpb;
     int64_t mod_ld;
     float eps;
+    int w_packed;  // skinny2: W in fragment-major 1-KiB blocks (kai0hip.h)
 };
 
 constexpr int TM = 64, TN = 32;
@@ -270,14 +271,24 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny_kernel(const SkinnyArgs p) 
 //   so the weight slice crosses the fabric once and is shared through that XCD's L2.
 //   NC = 128-wide chunks of K per wave (K = NW * NC * 128): 2 normally, 1 for the adaRMS variant (half the fragment registers per
 //   wave, twice the waves).
-template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true>
+//   ALDS: the A rows of the block go through LDS — read from global as contiguous 1-KiB runs (64 lanes x 16 B along a row), written
+//   to LDS with 16 B of row padding, MFMA fragments read back with ds_read_b128.  Every block of a launch reads the same few
+//   hundred KB of activations out of L2, and the direct fragment pattern (16 rows x 64 B per wave-instruction) gets 31-34 GB/s
+//   per CU there against 80-90 GB/s for contiguous runs (tools/probes/frag_load.hip: 128 KB per CU 4.8 vs 2.8 us, 256 KB 8.2 vs
+//   3.3 us): in the 1024-column projections the A operand, not the weight stream, was the longer load.
+template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false>
 __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p) {
     constexpr int TMB = 16 * MTL;
     constexpr int TN2 = PAIR ? 32 : 16;
     constexpr int LD2 = TN2 + 1;
+    constexpr int KB = NW * NC * 128;               // the contraction width this instantiation is built for
+    constexpr int A_ROWB = KB * 2 + 16;             // ALDS: bytes per A row in LDS (16 B of padding: conflict-free b128 reads)
+    constexpr int A_BYTES = ALDS ? TMB * A_ROWB : 0;
+    constexpr int RED_BYTES = (int)sizeof(float) * NW * TMB * LD2;
     extern __shared__ __attribute__((aligned(16))) char sk2_smem[];
+    // ALDS: the partial-sum buffer aliases the A tile (a barrier separates the last fragment read from the first partial write)
     float (*red)[TMB][LD2] = reinterpret_cast<float (*)[TMB][LD2]>(sk2_smem);
-    float (*ssq)[TMB] = reinterpret_cast<float (*)[TMB]>(sk2_smem + sizeof(float) * NW * TMB * LD2);
+    float (*ssq)[TMB] = reinterpret_cast<float (*)[TMB]>(sk2_smem + (A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -303,8 +314,13 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
 
     // contraction index of (lane group g, load j, element e) inside a 128-chunk: 32 j + 8 g + e — the four lanes of a row fetch one
     // contiguous 64-byte sector per load instruction (the same permutation for A, W and the modulation vectors)
-    const bf16_t* w0 = p.W + (int64_t)(n_sub0 + i) * p.ldw + kw0 + 8 * g;
-    const bf16_t* w1 = p.W + (int64_t)(n_sub1 + i) * p.ldw + kw0 + 8 * g;
+    // W: row-major [N][ldw] (lane (i, g): row i of the 16-row group, 16 B at k = 32 j + 8 g of each 128-chunk), or fragment-major
+    // (kai0hip.h w_packed: one contiguous KiB per 16 rows x 32 k — the lane's 16 B at lane * 16 of block (tile, k / 32))
+    const int64_t wj = p.w_packed ? 512 : 32, wc = p.w_packed ? 2048 : 128;  // element strides of load j / chunk c
+    const bf16_t* w0 = p.w_packed ? p.W + ((int64_t)(n_sub0 >> 4) * (p.K >> 5) + (kw0 >> 5)) * 512 + lane * 8
+                                  : p.W + (int64_t)(n_sub0 + i) * p.ldw + kw0 + 8 * g;
+    const bf16_t* w1 = p.w_packed ? p.W + ((int64_t)(n_sub1 >> 4) * (p.K >> 5) + (kw0 >> 5)) * 512 + lane * 8
+                                  : p.W + (int64_t)(n_sub1 + i) * p.ldw + kw0 + 8 * g;
     const bf16_t* arow[MTL];
     bool aok[MTL];
 #pragma unroll
@@ -320,14 +336,42 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
         for (int j = 0; j < 4; ++j) {
             // WNT: streamed once by this block only -> non-temporal; shared by the row-tile blocks of an XCD -> keep it in L2
             if constexpr (WNT) {
-                wf[c][0][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w0 + c * 128 + 32 * j));
-                if constexpr (PAIR) wf[c][1][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + c * 128 + 32 * j));
+                wf[c][0][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w0 + c * wc + j * wj));
+                if constexpr (PAIR) wf[c][1][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + c * wc + j * wj));
             } else {
-                wf[c][0][j] = *reinterpret_cast<const bf16x8*>(w0 + c * 128 + 32 * j);
-                if constexpr (PAIR) wf[c][1][j] = *reinterpret_cast<const bf16x8*>(w1 + c * 128 + 32 * j);
+                wf[c][0][j] = *reinterpret_cast<const bf16x8*>(w0 + c * wc + j * wj);
+                if constexpr (PAIR) wf[c][1][j] = *reinterpret_cast<const bf16x8*>(w1 + c * wc + j * wj);
             }
         }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (ALDS) {
+        // the block's TMB x K tile of A: 16-B chunks, consecutive lanes on consecutive chunks of a row
+        constexpr int CPR = KB / 8;                         // chunks per row
+        constexpr int NCH = TMB * CPR / (NW * 64);          // chunks per thread
+        static_assert((TMB * CPR) % (NW * 64) == 0, "A tile must divide over the block's threads");
+        bf16x8 ch[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int cidx = q * (NW * 64) + tid;
+            const int r = cidx / CPR, c8 = cidx - r * CPR;
+            const int row = m0 + r;
+            ch[q] = row < m_end ? *reinterpret_cast<const bf16x8*>(p.A + p.amap(row) * p.lda + c8 * 8) : zero8;
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int cidx = q * (NW * 64) + tid;
+            const int r = cidx / CPR, c8 = cidx - r * CPR;
+            *reinterpret_cast<bf16x8*>(sk2_smem + r * A_ROWB + c8 * 16) = ch[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    af[c][mt][j] = *reinterpret_cast<const bf16x8*>(sk2_smem + (mt * 16 + i) * A_ROWB + (kw0 + 8 * g + c * 128 + 32 * j) * 2);
+    } else {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -335,6 +379,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 af[c][mt][j] = aok[mt] ? *reinterpret_cast<const bf16x8*>(arow[mt] + c * 128 + 32 * j) : zero8;
+    }
 
     if constexpr (ADA) {
         // row statistics: this wave's 256 of the row's K = D elements, then the NW waves' partials through LDS (fixed order)
@@ -396,6 +441,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
 #pragma unroll
                 for (int s2 = 0; s2 < (PAIR ? 2 : 1); ++s2)
                     acc[mt][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c][mt][j], wf[c][s2][j], acc[mt][s2], 0, 0, 0);
+    if constexpr (ALDS) __syncthreads();  // `red` aliases the A tile: every wave has its fragments in registers by now
 #pragma unroll
     for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
@@ -444,16 +490,17 @@ KAI0_API int64_t kai0_skinny_workspace_bytes(int M, int N, int split_k) {
 
 namespace {
 
-template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true>
+template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false>
 int launch_skinny2(const SkinnyArgs& a, hipStream_t s) {
     constexpr int TMB = 16 * MTL, LD2 = (PAIR ? 32 : 16) + 1;
-    constexpr int LDS = (int)sizeof(float) * NW * TMB * (LD2 + 1);
+    constexpr int RED = (int)sizeof(float) * NW * TMB * LD2, ATILE = ALDS ? TMB * (NW * NC * 128 * 2 + 16) : 0;
+    constexpr int LDS = (ATILE > RED ? ATILE : RED) + (int)sizeof(float) * NW * TMB;
     static_assert(LDS <= 160 * 1024, "skinny2: LDS");
     // ADA: row tiles per batch entry (see the kernel)
     const int mtiles = ADA ? ((a.M + a.mod_rpb - 1) / a.mod_rpb) * ((a.mod_rpb + TMB - 1) / TMB) : (a.M + TMB - 1) / TMB;
     const dim3 grid(a.N / (PAIR ? 32 : 16), 1, mtiles);
-    auto kern = skinny2_kernel<NW, MTL, PAIR, ADA, NC, WNT>;
-    if constexpr (LDS > 64 * 1024) {
+    auto kern = skinny2_kernel<NW, MTL, PAIR, ADA, NC, WNT, ALDS>;
+    if constexpr (LDS > 48 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -491,6 +538,12 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
             if (nw == 8) return launch_skinny2<4, 1, false, false, 4, false>(a, s);
             if (nw == 16) return launch_skinny2<8, 1, false, false, 4, false>(a, s);
         }
+        static const int alds = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 1; }();
+        if (alds & 1) {  // A rows through LDS (see the kernel)
+            if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false, true>(a, s);
+            if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false, true>(a, s);
+            return launch_skinny2<16, 1, false, false, 2, false, true>(a, s);
+        }
         if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false>(a, s);
         if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false>(a, s);
         return launch_skinny2<16, 1, false, false, 2, false>(a, s);
@@ -502,6 +555,12 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
     if (ada && pv == 2) return launch_skinny2<8, 1, true, true, 1, false>(a, s);
     if (ada && pv == 3) return launch_skinny2<4, 2, true, true, 2, false>(a, s);
     if (ada && pv == 4) return launch_skinny2<4, 1, true, true, 2, false>(a, s);
+    static const int alds2 = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 1; }();
+    if (ada && (alds2 & 2)) {
+        // the adaRMS prologue reads A with identity rows (a_rpb == 0), so the coalesced tile load applies as is
+        if (pv == 3) return launch_skinny2<4, 2, true, true, 2, false, true>(a, s);
+        if (pv == 0) return launch_skinny2<8, 4, true, true, 1, true, true>(a, s);
+    }
     return ada ? launch_skinny2<8, 4, true, true, 1>(a, s) : launch_skinny2<4, 4, true, false>(a, s);
 }
 
@@ -561,6 +620,8 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
     a.rope_cos = d->rope_cos;
     a.rope_sin = d->rope_sin;
     a.rope_half = d->rope_half > 0 ? d->rope_half : ps;
+    KAI0_REQUIRE(!d->w_packed || (inblock && d->K % 32 == 0 && d->N % 16 == 0), "kai0_gemm_skinny_bf16: w_packed needs split_k == -1");
+    a.w_packed = d->w_packed;
     if (inblock) return skinny_inblock(d, a, (hipStream_t)stream);
     KAI0_REQUIRE(d->mod == nullptr, "kai0_gemm_skinny_bf16: the adaRMS prologue needs split_k == -1");
     const int tiles = d->N / TN, mtiles = (d->M + TM - 1) / TM;

@@ -102,7 +102,8 @@ class InferenceEngine:
         vt = self.pe.paligemma.model.vision_tower.vision_model
         lm = self.pe.paligemma.model.language_model
         srcs = [w for l in ex.layers for w in (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
-                                                l.mlp.gate_proj.weight, l.mlp.up_proj.weight)]  # fmt: skip
+                                                l.mlp.gate_proj.weight, l.mlp.up_proj.weight, l.self_attn.o_proj.weight,
+                                                l.mlp.down_proj.weight)]  # fmt: skip
         srcs += [w for l in lm.layers for w in (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight)]
         for l in vt.encoder.layers:
             at = l.self_attn
@@ -190,6 +191,11 @@ class InferenceEngine:
         self.w_qkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
                       for l in ex.layers]  # fmt: skip
         self.w_gu = [torch.cat([l.mlp.gate_proj.weight, l.mlp.up_proj.weight], 0).contiguous() for l in ex.layers]
+        # in-block kernels stream the weights as fragment-major 1-KiB blocks (ops.pack_skinny_weight): every wave-instruction of
+        # the stream is one contiguous KiB instead of sixteen 64-B pieces of sixteen rows
+        self.packed = os.environ.get("KAI0_SK2_PACKED", "1") != "0"
+        self.w_o = [l.self_attn.o_proj.weight for l in ex.layers]
+        self.w_d = [l.mlp.down_proj.weight for l in ex.layers]
         # o_proj / down_proj: split-K partial products, finished by adarms_combine
         self.S_o, self.S_d = ops.skinny_split_k(De, H * HD), ops.skinny_split_k(De, self.F)
         self.ws_o = ops.skinny_workspace(M, De, self.S_o, dev)
@@ -197,6 +203,12 @@ class InferenceEngine:
         # (superseded for K in {1024, 2048, 4096}: the in-block kernels below need neither partial products nor a combine launch)
         self.inblock = (os.environ.get("KAI0_INFER_INBLOCK", "1") != "0" and De == 1024 and NQ_ok(H * HD) and self.F in (1024, 2048, 4096)
                         and De % 128 == 0)  # fmt: skip
+        self.packed = self.packed and self.inblock and HD == 256 and self.S <= 1024 and self.P % 8 == 0  # (= the in-block stack runs)
+        if self.packed:
+            self.w_qkv = [ops.pack_skinny_weight(w) for w in self.w_qkv]
+            self.w_gu = [ops.pack_skinny_weight(w) for w in self.w_gu]
+            self.w_o = [ops.pack_skinny_weight(w) for w in self.w_o]
+            self.w_d = [ops.pack_skinny_weight(w) for w in self.w_d]
         # all 37 adaRMS `dense` layers stacked: the modulations of every layer and step come out of ONE f32 GEMM
         dens = [m for l in ex.layers for m in (l.input_layernorm.dense, l.post_attention_layernorm.dense)] + [ex.norm.dense]
         self.w_mod = torch.cat([m.weight for m in dens], 0).contiguous()
@@ -335,21 +347,21 @@ class InferenceEngine:
                             segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
                                   (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
                             c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, mod=mods[l][0][rows], mod_ld=ld,
-                            mod_rpb=Hs, eps=layer.input_layernorm.eps)  # fmt: skip
+                            mod_rpb=Hs, eps=layer.input_layernorm.eps, w_packed=self.packed)  # fmt: skip
             ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
                             rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
                             vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
             x1 = torch.empty((M, De), dtype=BF16, device=dev)
-            ops.skinny_gemm(self.att_buf, layer.self_attn.o_proj.weight, M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
+            ops.skinny_gemm(self.att_buf, self.w_o[l], M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
                             a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
-                            residual=xs, ldr=De)  # fmt: skip
+                            residual=xs, ldr=De, w_packed=self.packed)  # fmt: skip
             h = torch.empty((M, F), dtype=BF16, device=dev)
             ops.skinny_gemm(x1, self.w_gu[l], M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
                             segs=[(h, F, 0, F, 0)], mod=mods[l][1][rows], mod_ld=ld, mod_rpb=Hs,
-                            eps=layer.post_attention_layernorm.eps)  # fmt: skip
+                            eps=layer.post_attention_layernorm.eps, w_packed=self.packed)  # fmt: skip
             xs = torch.empty((M, De), dtype=BF16, device=dev)
-            ops.skinny_gemm(h, layer.mlp.down_proj.weight, M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
-                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De)  # fmt: skip
+            ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
+                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=self.packed)  # fmt: skip
         out, _ = ops.adarms(xs, mf[rows].contiguous(), Hs, self.pe.gemma_expert.model.norm.eps)
         return out
 

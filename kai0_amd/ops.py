@@ -133,9 +133,10 @@ def skinny_workspace(M: int, N: int, split_k: int, device) -> torch.Tensor:
 def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int = 0, pair_stride: int = 16, segs=None,
                 split_k: int = 1, workspace=None, a_map=None, c_map=None, gate=None, gate_rpb: int = 0, gate_ld: int = 0,
                 residual=None, ldr: int = 0, rope_cos=None, rope_sin=None, rope_half: int = 0, mod=None, mod_ld: int = 0,
-                mod_rpb: int = 0, eps: float = 1e-6):  # fmt: skip
+                mod_rpb: int = 0, eps: float = 1e-6, w_packed: bool = False):  # fmt: skip
     """kai0_gemm_skinny_bf16.  segs = [(dst, ld, n_begin, n_end, rope)].  split_k = -1: the whole contraction inside one block
-    (no partial products); with `mod` (f32 view [b][>= 2K], row stride mod_ld) the A operand is adaRMS-normalised on the fly."""
+    (no partial products); with `mod` (f32 view [b][>= 2K], row stride mod_ld) the A operand is adaRMS-normalised on the fly;
+    `w_packed`: W is the output of `pack_skinny_weight` (fragment-major 1-KiB blocks)."""
     for t in (A, W):
         if not t.is_cuda or t.dtype != BF16:
             raise _lib.Kai0HipError("skinny_gemm: expected bf16 CUDA (HIP) tensors; the product path has no CPU fallback")
@@ -143,6 +144,7 @@ def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int =
     d.A, d.W, d.lda, d.ldw = A.data_ptr(), W.data_ptr(), lda, ldw
     d.M, d.N, d.K = M, N, K
     d.pair_stride, d.mode, d.split_k = pair_stride, mode, split_k
+    d.w_packed = int(w_packed)
     if a_map:
         d.a_rpb, d.a_bs, d.a_off = a_map
     if c_map:
@@ -167,6 +169,16 @@ def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int =
             raise _lib.Kai0HipError("skinny_gemm: mod must be an f32 CUDA (HIP) tensor with unit inner stride")
         d.mod, d.mod_ld, d.mod_rpb, d.eps = mod.data_ptr(), mod_ld, mod_rpb, eps
     _lib.call("kai0_gemm_skinny_bf16", C.byref(d), _stream())
+
+
+def pack_skinny_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] row-major -> the fragment-major layout kai0_gemm_skinny_bf16 streams with `w_packed` (kai0hip.h): for every 16-row
+    tile t and 32-wide contraction step s one contiguous 1-KiB block holding W[16 t + i][32 s + 8 g + e] at (i + 16 g) * 8 + e.
+    A copy made once per inference engine: the weights stay the checkpoint-visible parameters."""
+    N, K = w.shape
+    if N % 16 or K % 32:
+        raise ValueError(f"pack_skinny_weight: N % 16 == 0 and K % 32 == 0 required, got {tuple(w.shape)}")
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
 def adarms_combine(partials, gate_prev, residual, mod, rows_per_batch: int, eps: float = 1e-6):

@@ -971,3 +971,46 @@ def test_skinny_inblock_adarms_prologue(ops, B):
     h2 = torch.zeros(M, F, dtype=BF16, device=dev())
     ops.skinny_gemm(y_ref, wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, split_k=-1, segs=[(h2, F, 0, F, 0)])
     assert rel_err(h2, h_ref) < 2e-3 and float((h2 != h_ref).float().mean()) < 2e-2
+
+
+def test_skinny_inblock_packed_weights_are_bit_identical(ops):
+    """`w_packed` (fragment-major 1-KiB blocks, ops.pack_skinny_weight) only changes where the weight stream is read from: every
+    in-block variant — plain + gated residual (K = 1024 / 2048 / 4096), adaRMS + q|k|v + RoPE, adaRMS + gate|up + GeGLU — must
+    return the bits of the row-major launch."""
+    Hs, P, S_ld, H, HD, F = 50, 30, 88, 8, 256, 4096
+    B = 2
+    M = B * Hs
+    for K, N in ((1024, 1024), (2048, 1024), (4096, 1024), (2048, 128)):
+        a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+        gate, res = rnd(B, N, seed=3), rnd(M, N, seed=4)
+        outs = []
+        for wp, packed in ((w, False), (ops.pack_skinny_weight(w), True)):
+            out = torch.full((M, N), float("nan"), dtype=BF16, device=dev())
+            ops.skinny_gemm(a, wp, M=M, N=N, K=K, lda=K, ldw=K, split_k=-1, segs=[(out, N, 0, N, 0)], gate=gate, gate_rpb=Hs,
+                            gate_ld=N, residual=res, ldr=N, w_packed=packed)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (K, N)
+    K = 1024
+    x = rnd(M, K, seed=1)
+    mod = rnd(B, 3 * K, dtype=F32, seed=9, scale=0.3)
+    wqkv = rnd((H + 2) * HD, K, seed=2, scale=0.05)
+    wgu = rnd(2 * F, K, seed=3, scale=0.05)
+    pos = (torch.arange(M, device=dev(), dtype=torch.int32) % Hs + 700).view(B, Hs).contiguous()
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, HD, 2, device=dev(), dtype=F32) / HD))).to(BF16).float()
+    cos, sin = ops.rope_table(pos, inv_freq)
+    N = (H + 2) * HD
+    got = []
+    for packed in (False, True):
+        q = torch.zeros(B, S_ld, H * HD, dtype=BF16, device=dev())
+        k = torch.zeros(B, S_ld, HD, dtype=BF16, device=dev())
+        vt = torch.zeros(B, HD, S_ld, dtype=BF16, device=dev())
+        ops.skinny_gemm(x, ops.pack_skinny_weight(wqkv) if packed else wqkv, M=M, N=N, K=K, lda=K, ldw=K, mode=1, pair_stride=HD // 2,
+                        segs=[(q, H * HD, 0, H * HD, 1), (k, HD, H * HD, H * HD + HD, 1), (vt, S_ld, H * HD + HD, N, 2)],
+                        c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, split_k=-1, mod=mod, mod_ld=3 * K,
+                        mod_rpb=Hs, eps=1e-6, w_packed=packed)
+        h = torch.zeros(M, F, dtype=BF16, device=dev())
+        ops.skinny_gemm(x, ops.pack_skinny_weight(wgu) if packed else wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F,
+                        split_k=-1, segs=[(h, F, 0, F, 0)], mod=mod, mod_ld=3 * K, mod_rpb=Hs, eps=1e-6, w_packed=packed)
+        got.append((q, k, vt, h))
+    for a_, b_, name in zip(got[0], got[1], ("q", "k", "vt", "h")):
+        assert torch.equal(a_, b_), name
