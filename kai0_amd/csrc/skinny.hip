@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
     // ALDS: the partial-sum buffer aliases the A tile (a barrier separates the last fragment read from the first partial write)
     float (*red)[TMB][LD2] = reinterpret_cast<float (*)[TMB][LD2]>(sk2_smem);
     float (*ssq)[TMB] = reinterpret_cast<float (*)[TMB]>(sk2_smem + (A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES));
+    // ALDS + ADA: the entry's scale | shift vectors (2 K f32) are requested at kernel entry, one 16-B piece per thread, and wait in
+    // LDS behind the row statistics (read from global after the statistics they were a second, dependent memory round trip)
+    float* mod_lds = reinterpret_cast<float*>(sk2_smem + (A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES) + sizeof(float) * NW * TMB);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -344,6 +347,15 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
             }
         }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 mod_piece[(ALDS && ADA) ? (2 * KB / 4 + NW * 64 - 1) / (NW * 64) : 1];
+    if constexpr (ALDS && ADA) {
+        const float* mrow = p.mod + (int64_t)(m0 / p.mod_rpb) * p.mod_ld;
+#pragma unroll
+        for (int q = 0; q < (2 * KB / 4 + NW * 64 - 1) / (NW * 64); ++q) {
+            const int idx = q * (NW * 64) + tid;  // 16-B piece of [scale (K) | shift (K)]
+            mod_piece[q] = idx < 2 * KB / 4 ? *reinterpret_cast<const f32x4*>(mrow + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     if constexpr (ALDS) {
         // the block's TMB x K tile of A: 16-B chunks, consecutive lanes on consecutive chunks of a row
         constexpr int CPR = KB / 8;                         // chunks per row
@@ -362,6 +374,13 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
             const int cidx = q * (NW * 64) + tid;
             const int r = cidx / CPR, c8 = cidx - r * CPR;
             *reinterpret_cast<bf16x8*>(sk2_smem + r * A_ROWB + c8 * 16) = ch[q];
+        }
+        if constexpr (ADA) {
+#pragma unroll
+            for (int q = 0; q < (2 * KB / 4 + NW * 64 - 1) / (NW * 64); ++q) {
+                const int idx = q * (NW * 64) + tid;
+                if (idx < 2 * KB / 4) *reinterpret_cast<f32x4*>(mod_lds + idx * 4) = mod_piece[q];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
             for (int w = 0; w < NW; ++w) ss += ssq[w][mt * 16 + i];
             rstd[mt] = rsqrtf(ss / (float)p.K + p.eps);
         }
-        const float* mrow = p.mod + (int64_t)(m0 / p.mod_rpb) * p.mod_ld + kw0 + 8 * g;
+        const float* mrow = (ALDS ? mod_lds : p.mod + (int64_t)(m0 / p.mod_rpb) * p.mod_ld) + kw0 + 8 * g;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -494,7 +513,7 @@ template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, boo
 int launch_skinny2(const SkinnyArgs& a, hipStream_t s) {
     constexpr int TMB = 16 * MTL, LD2 = (PAIR ? 32 : 16) + 1;
     constexpr int RED = (int)sizeof(float) * NW * TMB * LD2, ATILE = ALDS ? TMB * (NW * NC * 128 * 2 + 16) : 0;
-    constexpr int LDS = (ATILE > RED ? ATILE : RED) + (int)sizeof(float) * NW * TMB;
+    constexpr int LDS = (ATILE > RED ? ATILE : RED) + (int)sizeof(float) * NW * TMB + ((ALDS && ADA) ? 2 * NW * NC * 128 * 4 : 0);
     static_assert(LDS <= 160 * 1024, "skinny2: LDS");
     // ADA: row tiles per batch entry (see the kernel)
     const int mtiles = ADA ? ((a.M + a.mod_rpb - 1) / a.mod_rpb) * ((a.mod_rpb + TMB - 1) / TMB) : (a.M + TMB - 1) / TMB;
@@ -538,7 +557,7 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
             if (nw == 8) return launch_skinny2<4, 1, false, false, 4, false>(a, s);
             if (nw == 16) return launch_skinny2<8, 1, false, false, 4, false>(a, s);
         }
-        static const int alds = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 1; }();
+        static const int alds = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 3; }();
         if (alds & 1) {  // A rows through LDS (see the kernel)
             if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false, true>(a, s);
             if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false, true>(a, s);
@@ -555,7 +574,7 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
     if (ada && pv == 2) return launch_skinny2<8, 1, true, true, 1, false>(a, s);
     if (ada && pv == 3) return launch_skinny2<4, 2, true, true, 2, false>(a, s);
     if (ada && pv == 4) return launch_skinny2<4, 1, true, true, 2, false>(a, s);
-    static const int alds2 = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 1; }();
+    static const int alds2 = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 3; }();
     if (ada && (alds2 & 2)) {
         // the adaRMS prologue reads A with identity rows (a_rpb == 0), so the coalesced tile load applies as is
         if (pv == 3) return launch_skinny2<4, 2, true, true, 2, false, true>(a, s);

@@ -15,11 +15,17 @@ __global__ __launch_bounds__(1024) void frag_load(const char* __restrict__ base,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const char* blk = base + (SHARED ? 0 : (int64_t)blockIdx.x * per_block);
     u32x4 v[NL];
-    if (MODE == 0) {
+    if constexpr (MODE == 0) {
         // the wave owns K bytes [wave * NL * 64, ...) of 16 rows: row stride ld
         const char* p = blk + (int64_t)(lane & 15) * ld + (int64_t)wave * NL * 64 + (lane >> 4) * 16;
 #pragma unroll
         for (int j = 0; j < NL; ++j) v[j] = *reinterpret_cast<const u32x4*>(p + j * 64);
+    } else if constexpr (MODE >= 2) {
+        // MODE = rows per instruction (8, 4, 2): R rows x (1024 / R) contiguous bytes; the wave owns K bytes [wave * NL * 1024 / R, ...) of R rows
+        constexpr int R = MODE >= 2 ? MODE : 2, SEG = 1024 / R, LPR = SEG / 16;
+        const char* p = blk + (int64_t)(lane / LPR) * ld + (int64_t)wave * NL * SEG + (lane % LPR) * 16;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) v[j] = *reinterpret_cast<const u32x4*>(p + j * SEG);
     } else {
         const char* p = blk + (int64_t)wave * NL * 1024 + lane * 16;
 #pragma unroll
@@ -60,6 +66,15 @@ int main() {
            run<NL, 0, false>(buf, per_block, NL * W * 64, out, W, 200), run<NL, 0, true>(buf, per_block, NL * W * 64, out, W, 200)); \
     printf("1 KiB contiguous (%2d loads x %2d waves) %6d   %8.2f   %8.2f\n", NL, W, NL * W,                                       \
            run<NL, 1, false>(buf, per_block, 0, out, W, 200), run<NL, 1, true>(buf, per_block, 0, out, W, 200));
+#define ROWR(R, NL, W)                                                                                                          \
+    printf("%d rows x %4d B  (%2d loads x %2d waves) %6d   %8.2f   %8.2f\n", R, 1024 / R, NL, W, NL * W,                          \
+           run<NL, R, false>(buf, per_block, NL * W * (1024 / R), out, W, 200), run<NL, R, true>(buf, per_block, NL * W * (1024 / R), out, W, 200));
+    ROWR(8, 16, 16)
+    ROWR(4, 16, 16)
+    ROWR(2, 16, 16)
+    ROWR(8, 8, 16)
+    ROWR(4, 8, 16)
+    ROWR(2, 8, 16)
     ROW(8, 4)
     ROW(16, 4)
     ROW(8, 16)
