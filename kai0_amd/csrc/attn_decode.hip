@@ -54,6 +54,9 @@ __device__ __forceinline__ void dec_wave_sync() {
 }
 
 // ---- kernel 1: masked, scaled, bf16-rounded logits L[b][row][key] (-inf where hidden) ----------------------------
+// NG = 32-key groups per wave: 2 (four key ranges of 256 per query tile) or 1 (eight ranges of 128: twice the blocks, half the rows
+// each wave stages)
+template <int NG>
 __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t* __restrict__ L, int64_t l_bs) {
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -66,18 +69,18 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
     // this wave's 64 keys (two 32-key groups) as 32 contiguous 1-KiB reads: instruction q covers key rows 2q, 2q + 1.  Rows 16-31
     // of each 32-row group are stored with their 16-B column index xor 4: the fragment reads below touch rows {0-3, 8-11, 16-19,
     // 24-27} of a group per 16 lanes, and with a 528-B row stride rows r and r + 16 would share their banks.
-    const int key0 = (blockIdx.y * 8 + wave * 2) * 32;
+    const int key0 = (blockIdx.y * 4 + wave) * NG * 32;
     const bf16_t* Kb = p.K + (int64_t)b * p.k_bs;
     {
         const int sub = lane >> 5, c16 = lane & 31;
-        bf16x8 ch[32];
+        bf16x8 ch[16 * NG];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < 16 * NG; ++q) {
             const int row = 2 * q + sub;
             ch[q] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)min(key0 + row, p.k_rows - 1) * p.k_ld + c16 * 8);
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < 16 * NG; ++q) {
             const int row = 2 * q + sub;
             *reinterpret_cast<bf16x8*>(my + row * DEC_ROWB + ((c16 ^ ((row & 16) >> 2)) << 4)) = ch[q];
         }
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
     // qc: INT_MIN hides everything (row outside the problem); without codes every real key is visible
     const int qc = qok ? (p.qcode ? p.qcode[(int64_t)b * p.qc_ld + p.q0 + rq / p.H] : INT_MAX - 1) : INT_MIN;
     const int arow = 8 * (i >> 2) + (i & 3);  // key (within the group) fed to A-row i of tile 0; tile 1: + 4
-    int kc[2][8];
+    int kc[NG][8];
 #pragma unroll
-    for (int gl = 0; gl < 2; ++gl) {
+    for (int gl = 0; gl < NG; ++gl) {
         const int base = key0 + gl * 32;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {  // unconditional (clamped) loads: all in flight together
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
     }
     dec_wave_sync();
 #pragma unroll
-    for (int gl = 0; gl < 2; ++gl) {
+    for (int gl = 0; gl < NG; ++gl) {
         const int base = key0 + gl * 32;
         const int ra = gl * 32 + arow, rb = ra + 4;
         const char* pa = my + ra * DEC_ROWB;
@@ -129,6 +132,8 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
 }
 
 // ---- kernel 2: f32 softmax of the stored logits, P bf16, O = P V for a 64-wide slice of the head dim ------------------
+// HT = 16-wide head-dim tiles per block: 4 (four 64-wide slices per query tile) or 2 (eight 32-wide slices)
+template <int HT>
 __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16_t* __restrict__ L, int64_t l_bs) {
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     float (*red)[16][64 + 4] = reinterpret_cast<float (*)[16][64 + 4]>(dec_smem + 4 * DEC_STAGE);
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, r0 = blockIdx.x * 16, h0 = blockIdx.y * 64;
+    const int b = blockIdx.z, r0 = blockIdx.x * 16, h0 = blockIdx.y * (16 * HT);
     const int ngroups = (p.Sk + 31) >> 5;
     // wave w owns the 256 keys [256 w, 256 w + 256) = key groups 8 w .. 8 w + 7; lane (q, g) keys 8g..8g+7 of each group
     // logits of row r0 + i
@@ -151,11 +156,11 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
         const int sub = lane >> 5, c16 = lane & 31;
         const int kcol = min(wave * 256 + c16 * 8, (int)p.vt_ld - 8);  // (keys past the padded row end: never multiplied, P = 0)
         const bf16_t* Vb = p.Vt + (int64_t)b * p.vt_bs + (int64_t)h0 * p.vt_ld + kcol;
-        bf16x8 ch[32];
+        bf16x8 ch[8 * HT];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) ch[q] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)(2 * q + sub) * p.vt_ld);
+        for (int q = 0; q < 8 * HT; ++q) ch[q] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)(2 * q + sub) * p.vt_ld);
 #pragma unroll
-        for (int q = 0; q < 32; ++q) *reinterpret_cast<bf16x8*>(my + (2 * q + sub) * DEC_ROWB + (c16 << 4)) = ch[q];
+        for (int q = 0; q < 8 * HT; ++q) *reinterpret_cast<bf16x8*>(my + (2 * q + sub) * DEC_ROWB + (c16 << 4)) = ch[q];
     }
     float s[8][8];
     float m = -INFINITY;
@@ -187,9 +192,9 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
     __syncthreads();  // (also: every lane's staged value rows are in LDS — the ds_writes above were waited for by the barrier's lgkmcnt)
     sum = (sstat[1][0][i] + sstat[1][1][i]) + (sstat[1][2][i] + sstat[1][3][i]);
     const float inv = (m > -INFINITY && sum > 0.f) ? 1.0f / sum : 0.f;
-    f32x4 acc[4];
+    f32x4 acc[HT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < HT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int gl = 0; gl < 8; ++gl) {
         const bool live = wave * 8 + gl < ngroups;
@@ -197,17 +202,17 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = f2bf((live && m > -INFINITY) ? s[gl][e] * inv : 0.f);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < HT; ++t) {
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(my + (16 * t + i) * DEC_ROWB + ((4 * gl + g) << 4));
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[t], 0, 0, 0);
         }
     }
     // acc[t]: lane (q = i, g) holds hd = h0 + 16t + 4g + reg
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&red[wave][i][16 * t + 4 * g]) = acc[t];
+    for (int t = 0; t < HT; ++t) *reinterpret_cast<f32x4*>(&red[wave][i][16 * t + 4 * g]) = acc[t];
     __syncthreads();
-    const int q = tid >> 4, part = tid & 15;  // 16 rows x 16 pieces of 4 columns
-    if (r0 + q < p.rows) {
+    const int q = tid / (4 * HT), part = tid % (4 * HT);  // 16 rows x 4 HT pieces of 4 columns
+    if (tid < 64 * HT && r0 + q < p.rows) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -247,14 +252,26 @@ KAI0_API int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void
     const int64_t l_bs = (int64_t)qt * 16 * DEC_KEYS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dec_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LOGITS_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_PV_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)dec_logits_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LOGITS_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_logits_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LOGITS_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_pv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_PV_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_pv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_PV_LDS);
         KAI0_REQUIRE(e == hipSuccess, "kai0_attn_decode: cannot reserve %d B of LDS: %s", DEC_PV_LDS, hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(dec_logits_kernel, dim3(qt, DEC_KSPLIT, batch), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
-                       (bf16_t*)workspace, l_bs);
-    hipLaunchKernelGGL(dec_pv_kernel, dim3(qt, DEC_HSPLIT, batch), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
-                       (const bf16_t*)workspace, l_bs);
+    // few query tiles (B = 1: 25): eight key ranges / eight head-dim slices per tile instead of four, so that 200 blocks share
+    // the staging of the caches instead of 100
+    static const int fine = [] { const char* e = getenv("KAI0_DEC_FINE"); return e ? atoi(e) : 1; }();
+    if (fine && (int64_t)qt * batch <= 32) {
+        hipLaunchKernelGGL(dec_logits_kernel<1>, dim3(qt, 2 * DEC_KSPLIT, batch), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
+                           (bf16_t*)workspace, l_bs);
+        hipLaunchKernelGGL(dec_pv_kernel<2>, dim3(qt, 2 * DEC_HSPLIT, batch), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
+                           (const bf16_t*)workspace, l_bs);
+    } else {
+        hipLaunchKernelGGL(dec_logits_kernel<2>, dim3(qt, DEC_KSPLIT, batch), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
+                           (bf16_t*)workspace, l_bs);
+        hipLaunchKernelGGL(dec_pv_kernel<4>, dim3(qt, DEC_HSPLIT, batch), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
+                           (const bf16_t*)workspace, l_bs);
+    }
     return kai0_check_launch("kai0_attn_decode");
 }
