@@ -244,3 +244,28 @@ def test_cabi_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     assert lib.kai0_abi_version() == 1
     assert ctypes.sizeof(_lib.GemmDesc) == lib.kai0_gemm_desc_size()
+
+
+def test_pack_skinny_weight_layout():
+    """ops.pack_skinny_weight == the fragment-major layout kai0hip.h documents for `kai0_skinny_desc.w_packed`: for the 16-row
+    tile t and the 32-wide contraction step s one contiguous block of 512 elements at (t * (K / 32) + s) * 512 holding
+    W[16 t + i][32 s + 8 g + e] at (i + 16 g) * 8 + e (pure index arithmetic: runs without a GPU)."""
+    import torch
+
+    from kai0_amd import ops
+
+    N, K = 48, 96
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K)
+    p = ops.pack_skinny_weight(w).reshape(-1)
+    assert p.numel() == N * K and sorted(p.tolist()) == sorted(w.reshape(-1).tolist())
+    for t in range(N // 16):
+        for s in range(K // 32):
+            blk = p[(t * (K // 32) + s) * 512 : (t * (K // 32) + s + 1) * 512]
+            for i in (0, 7, 15):
+                for g in range(4):
+                    for e in (0, 3, 7):
+                        assert blk[(i + 16 * g) * 8 + e] == w[16 * t + i, 32 * s + 8 * g + e]
+    import pytest
+
+    with pytest.raises(ValueError):
+        ops.pack_skinny_weight(torch.zeros(40, 96))
