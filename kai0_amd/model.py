@@ -263,12 +263,20 @@ def build_mask_codes(pad_masks: torch.Tensor, att_masks: torch.Tensor):
 
 
 _EXPERT_STREAM = os.environ.get("KAI0_EXPERT_STREAM", "1") != "0"  # the action expert's chain on a second HIP stream
+_SKIP_DEAD_PREFIX = os.environ.get("KAI0_SKIP_DEAD_PREFIX", "1") != "0"  # last layer: no prefix o_proj / MLP (dead values)
 
 
 def set_expert_stream(on: bool) -> bool:
     """Switch the second stream of `forward_joint` on / off (bench.py times every GEMM launch alone); returns the old setting."""
     global _EXPERT_STREAM
     old, _EXPERT_STREAM = _EXPERT_STREAM, bool(on)
+    return old
+
+
+def set_skip_dead_prefix(on: bool) -> bool:
+    """Switch the elimination of the last layer's dead prefix o_proj / MLP on / off (tests); returns the old setting."""
+    global _SKIP_DEAD_PREFIX
+    old, _SKIP_DEAD_PREFIX = _SKIP_DEAD_PREFIX, bool(on)
     return old
 
 
@@ -389,7 +397,9 @@ class PaliGemmaWithExpertModel(nn.Module):
                 for t in ts:
                     t.record_stream(to)
 
-        def layer_fn(xp, xs, lp, le):
+        n_layers = len(lm.layers)
+
+        def layer_fn(xp, xs, lp, le, last=False):
             ap, ae = lp.self_attn, le.self_attn
             with on_side():
                 mod1 = ops.linear_f32(cond, le.input_layernorm.dense.weight, le.input_layernorm.dense.bias)
@@ -411,6 +421,12 @@ class PaliGemmaWithExpertModel(nn.Module):
                 xs, hs, gate2 = ops.adarms_res(xs, mod2, Hs, le.post_attention_layernorm.eps)
                 ys = ops.geglu_mlp(hs, le.mlp.gate_proj.weight, le.mlp.up_proj.weight, le.mlp.down_proj.weight)
                 xs = ops.gated_residual(xs, ys, gate2, Hs)
+            if last and _SKIP_DEAD_PREFIX:
+                # nothing reads the prefix stream after the last joint attention (the model's output is the suffix; the prefix's
+                # final norm has no consumer either): its o_proj, post-attention norm and MLP in the LAST layer are dead values —
+                # 0.2 TFLOP per sample that XLA removes from the reference's jitted JAX step and the inference engine never
+                # computed.  Their parameters receive no gradient either way (tests/test_model_gpu.py).
+                return xp, xs
             # prefix: o_proj + residual fused in the GEMM epilogue, then RMSNorm -> GeGLU MLP -> residual
             xp = _lin(att_p, ap.o_proj, residual=xp)
             xp, hp = ops.rmsnorm_res(xp, lp.post_attention_layernorm.weight, lp.post_attention_layernorm.eps)
@@ -426,7 +442,7 @@ class PaliGemmaWithExpertModel(nn.Module):
             hk.pre_forward(f"joint.{l}")
             if dual:
                 side.wait_stream(main)  # the unit's parameters may have just been completed on the main stream
-            xp, xs = self._maybe_remat(layer_fn, xp, xs, lp, le)
+            xp, xs = self._maybe_remat(layer_fn, xp, xs, lp, le, l == n_layers - 1)
             xp, xs = hk.post_forward(f"joint.{l}", xp, xs)
         hk.pre_forward("head")  # final adaRMS norm, action_out_proj (and the estimator's value head): never released early
         if dual:

@@ -425,3 +425,32 @@ def test_trainer_with_rccl_collectives_equals_collective_free_engine(pair, mode,
         dist.destroy_process_group()
     assert got[0] == base[0] and got[2] == base[2]
     assert all(torch.equal(a, b) for a, b in zip(got[1], base[1]))
+
+
+def test_dead_prefix_tail_of_the_last_layer_changes_nothing(pair):
+    """forward_joint does not compute the last layer's prefix o_proj / post-attention norm / MLP (nothing reads the prefix after
+    the last joint attention): loss and every gradient must be the bits of the run that computes them."""
+    from kai0_amd import model as M
+
+    m, dev = pair["model"], pair["dev"]
+    args = (pair["gobs"], pair["actions"].to(dev))
+    kw = dict(noise=pair["noise"].to(dev), time=pair["time"].to(dev))
+    res = {}
+    for on in (True, False):
+        old = M.set_skip_dead_prefix(on)
+        try:
+            m.zero_grad(set_to_none=True)
+            loss = m(*args, **kw)
+            loss.mean().backward()
+            torch.cuda.synchronize()
+            res[on] = (loss.detach().clone(), {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()})
+        finally:
+            M.set_skip_dead_prefix(old)
+    assert torch.equal(res[True][0], res[False][0])
+    for k, g in res[False][1].items():
+        h = res[True][1][k]
+        if g is None or float(g.abs().max()) == 0.0:
+            assert h is None or float(h.abs().max()) == 0.0, k
+        else:
+            assert h is not None and torch.equal(g, h), k
+    m.zero_grad(set_to_none=True)
