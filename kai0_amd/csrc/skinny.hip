@@ -568,13 +568,18 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
         return launch_skinny2<16, 1, false, false, 2, false>(a, s);
     }
     KAI0_REQUIRE(nw == 4, "kai0_gemm_skinny_bf16: in-block modes 1 / 2 are built for K = 1024 (got %d)", d->K);
-    static const int pv_all = [] { const char* e = getenv("KAI0_SK2_PAIR_VARIANT"); return e ? atoi(e) : 30; }();
+    // tens digit: q|k|v launch, ones digit: gate|up launch.  With the A rows staged through LDS (chunk of 10 Euler steps, one box):
+    // q|k|v as 8 waves x one 16-row tile per block (320 blocks; digit 2) 8.69 ms of denoise, 8 waves x two tiles (1) 8.60-8.70,
+    // 4 waves x two tiles (3, the choice before the staging) 8.83; gate|up keeps all four row tiles in one block (0)
+    static const int pv_all = [] { const char* e = getenv("KAI0_SK2_PAIR_VARIANT"); return e ? atoi(e) : 20; }();
     const int pv = d->mode == 1 ? pv_all / 10 : pv_all % 10;  // tens digit: q|k|v launch, ones digit: gate|up launch
     static const int alds2 = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 3; }();
     if (ada && (alds2 & 2)) {
         // the adaRMS prologue reads A with identity rows (a_rpb == 0), so the coalesced tile load applies as is
         if (pv == 3) return launch_skinny2<4, 2, true, true, 2, false, true>(a, s);
         if (pv == 0) return launch_skinny2<8, 4, true, true, 1, true, true>(a, s);
+        if (pv == 1) return launch_skinny2<8, 2, true, true, 1, false, true>(a, s);
+        if (pv == 2) return launch_skinny2<8, 1, true, true, 1, false, true>(a, s);
     }
     if (ada && pv == 1) return launch_skinny2<8, 2, true, true, 1, false>(a, s);
     if (ada && pv == 2) return launch_skinny2<8, 1, true, true, 1, false>(a, s);
