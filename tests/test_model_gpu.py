@@ -454,3 +454,31 @@ def test_dead_prefix_tail_of_the_last_layer_changes_nothing(pair):
         else:
             assert h is not None and torch.equal(g, h), k
     m.zero_grad(set_to_none=True)
+
+
+def test_trimmed_prompt_padding_gives_the_same_loss_and_gradients(pair):
+    """`model.trim_prompt_padding = True` cuts the prompt to the longest valid prompt of the batch: padded tokens are invisible
+    keys and unread rows, so loss and gradients may only move by summation order (other key-tile boundaries)."""
+    m, dev = pair["model"], pair["dev"]
+    obs = pair["gobs"]
+    mask = obs.tokenized_prompt_mask
+    assert int(mask.sum(1).max()) + 8 <= mask.shape[1], "the fixture needs padded prompt slots for this test"
+    args = (obs, pair["actions"].to(dev))
+    kw = dict(noise=pair["noise"].to(dev), time=pair["time"].to(dev))
+    res = {}
+    for trim in (False, True):
+        m.trim_prompt_padding = trim
+        try:
+            m.zero_grad(set_to_none=True)
+            loss = m(*args, **kw)
+            loss.mean().backward()
+            torch.cuda.synchronize()
+            res[trim] = (loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            m.trim_prompt_padding = False
+    assert rel(res[True][0], res[False][0]) < 2e-3
+    worst = max(rel(g, res[False][1][k]) for k, g in res[True][1].items() if float(res[False][1][k].float().norm()) > 1e-6)
+    print("trimmed vs full prompt: loss rel-L2", rel(res[True][0], res[False][0]), "worst gradient rel-L2", worst)
+    assert worst < 2e-2
+    assert set(res[True][1]) == set(res[False][1])
+    m.zero_grad(set_to_none=True)
