@@ -269,3 +269,24 @@ def test_pack_skinny_weight_layout():
 
     with pytest.raises(ValueError):
         ops.pack_skinny_weight(torch.zeros(40, 96))
+
+
+def test_trim_prompt_keeps_every_valid_token():
+    """PI0Pytorch._trim_prompt (opt-in training switch): the prompt is cut to the longest valid prompt of the batch, rounded up to 8
+    slots; nothing valid is dropped, a batch that uses all slots is returned as is."""
+    import torch
+
+    from kai0_amd.model import PI0Pytorch
+
+    tok = torch.arange(2 * 200).reshape(2, 200)
+    mask = torch.zeros(2, 200, dtype=torch.bool)
+    mask[0, :70] = True
+    mask[1, :101] = True
+    t, m = PI0Pytorch._trim_prompt(tok, mask)
+    assert t.shape == (2, 104) and m.shape == (2, 104) and t.is_contiguous()
+    assert torch.equal(t, tok[:, :104]) and int(m.sum()) == int(mask.sum())
+    mask[1, :] = True
+    t, m = PI0Pytorch._trim_prompt(tok, mask)
+    assert t is tok and m is mask
+    t, m = PI0Pytorch._trim_prompt(tok, torch.zeros(2, 200, dtype=torch.bool))
+    assert t.shape == (2, 8)
