@@ -283,8 +283,8 @@ def set_skip_dead_prefix(on: bool) -> bool:
 class _NoUnitHooks:
     """Default `unit_hooks`: the model announces each sharding unit (kai0_amd.sharded) to nobody."""
 
-    def pre_forward(self, unit: str):
-        pass
+    def pre_forward(self, unit: str) -> bool:
+        return False  # (the sharded engine returns True when the current stream had to wait for a parameter gather)
 
     def post_forward(self, unit: str, *tensors):
         return tensors
@@ -439,9 +439,12 @@ class PaliGemmaWithExpertModel(nn.Module):
             side.wait_stream(main)
             hand((xs, cond), side)
         for l, (lp, le) in enumerate(zip(lm.layers, ex.layers, strict=True)):
-            hk.pre_forward(f"joint.{l}")
-            if dual:
-                side.wait_stream(main)  # the unit's parameters may have just been completed on the main stream
+            gathered = hk.pre_forward(f"joint.{l}")
+            if dual and gathered:
+                # the unit's parameters were just completed behind a wait on the MAIN stream: the second stream must see them
+                # too.  Without a gather nothing orders layer l+1's expert chain behind the main stream's o_proj / MLP of layer l
+                # (its longest kernels) except the data it really needs.
+                side.wait_stream(main)
             xp, xs = self._maybe_remat(layer_fn, xp, xs, lp, le, l == n_layers - 1)
             xp, xs = hk.post_forward(f"joint.{l}", xp, xs)
         hk.pre_forward("head")  # final adaRMS norm, action_out_proj (and the estimator's value head): never released early

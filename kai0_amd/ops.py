@@ -365,6 +365,17 @@ def join_streams(device) -> None:
             cur.wait_stream(st)
 
 
+def reset_backward_state() -> None:
+    """Start of a training step: forget a main<-side join that a previous backward pass queued but never ran (the pass raised
+    before its final callbacks) — otherwise no later backward would queue the join again."""
+    for idx in list(_JOIN_PENDING):
+        if _JOIN_PENDING[idx]:
+            _JOIN_PENDING[idx] = False
+            pair = _DUAL.get(idx)
+            if pair is not None:
+                pair[0].wait_stream(pair[1])  # whatever that pass left on the second stream is ordered before this step
+
+
 def _note_side_gradient(param) -> None:
     """A gradient was just written in place (into the trainer's flat buffer) by a backward node running on the second stream:
     have the main stream pick it up when this backward pass ends (autograd itself only synchronises gradients it accumulates)."""

@@ -15,13 +15,20 @@ Two modes over the same buckets, collectives and kernels:
   * "fsdp" — parameters sharded too (training/sharding.py:48-102; north_star "optimizer/grad/param FSDP-style"): the
     persistent bf16 copy is the 1/N shard; a bucket's full parameters exist only around its use — gathered one bucket
     ahead of the forward, freed after it, gathered again one bucket ahead of the backward, freed when the bucket's
-    gradients have been reduce-scattered.  3 x (N-1)/N x 7.2 GB per step; saves (N-1)/N x 7.2 GB of HBM.
+    gradients have been reduce-scattered.  3 x (N-1)/N x 7.2 GB per step; saves (N-1)/N x 7.2 GB of HBM.  The full-size
+    gradient buffer of a bucket is a staging buffer in this mode: it exists from the start of the bucket's backward until
+    its reduce-scatter has finished (one bucket later) — only the 1/N gradient shard persists.
 
 Unit = what the model uses together (one SigLIP layer; one joint Gemma-2B + expert layer; the embeddings; the heads): the
 model reports them in forward-use order (`sharding_units()`), consecutive units are packed into buckets of ~512 MB, a
 bucket's reduce-scatter is issued from inside backward the moment its last gradient has been written (the backward shims
 write straight into the flat gradient buffer: no copy, no autograd accumulation).  SUM collectives only (the loss is
 scaled by 1/N), so the gloo tests on CPU drive exactly the call path RCCL runs.
+
+Evidence for the first multi-GPU run (`comm_profile = True`, read with `comm_report()`): every place where the compute
+stream has to wait for a collective (a parameter gather in pre_forward / pre_backward, the reduce-scatters and the norm
+all-reduce in step()) is bracketed by two events on the compute stream, so `comm_exposed_ms` is the time the chip sat in those
+waits — what overlap did NOT hide — next to the bytes each rank moved.
 
 The whole optimizer is 3 kernels per bucket on flat shards (sum of squares, clip coefficient kept on device, fused
 AdamW) — no per-tensor launches, no host sync.  The arithmetic is pluggable (`ShardOps`) only so the collective /
@@ -82,6 +89,10 @@ class _Bucket:
         self.fsdp = fsdp
         self.full_nbytes = self.flat_param.untyped_storage().nbytes()
         self.resident = True  # fsdp: whether flat_param's storage currently exists
+        self.grad_nbytes = self.flat_grad.untyped_storage().nbytes()
+        self.grad_resident = True  # fsdp: whether flat_grad's storage currently exists (staging buffer, see the module docstring)
+        self.grad_freeable = False  # fsdp: set once a step has shown that the bucket's backward announces itself first
+        self.announced = False      # this step: _pre_backward ran for the bucket's group before its first gradient arrived
         self.param_shard = None  # set by carve_shards() (after the construction-time broadcast)
         # one GPU: the "shard" is the whole buffer — alias it instead of copying
         self.grad_shard = self.flat_grad if alias_shard else torch.zeros(self.shard, dtype=dtype, device=device)
@@ -215,6 +226,9 @@ class ShardedDataParallel:
         self._coef = torch.ones(1, dtype=F32, device=self.device)
         self._norm = torch.zeros(1, dtype=F32, device=self.device)
         self._in_backward = False
+        self._rs_inflight: list[_Bucket] = []  # fsdp: buckets whose reduce-scatter runs out of a staging buffer
+        self.comm_profile = False
+        self._comm_events: list[tuple[str, object, object]] = []
         if fsdp:
             for g in range(len(self.groups)):
                 self._release(g)
@@ -238,6 +252,44 @@ class ShardedDataParallel:
             return None
         return dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True)
 
+    # ---- exposed-communication bookkeeping ----------------------------------------------------------------
+    def _wait(self, work, kind: str):
+        """`work.wait()` makes the CURRENT stream wait for the collective; with `comm_profile` the wait is bracketed by two
+        events on that stream: their distance is the time the compute stream stalled here (0 if the collective was done)."""
+        if work is None:
+            return
+        if self.comm_profile and self.device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            self._comm_events.append((kind, e0, e1))
+        else:
+            work.wait()
+
+    def comm_bytes_per_step(self) -> dict:
+        """Bytes this rank sends (= receives) per training step: ring-equivalent (N-1)/N of every bucket per collective."""
+        n = self.world
+        if not self.collectives or n <= 1:
+            return {"reduce_scatter": 0, "all_gather": 0, "total": 0}
+        full = sum(b.numel * b.flat_param.element_size() for b in self.buckets)
+        rs = full * (n - 1) // n
+        ag = rs * (2 if self.mode == "fsdp" else 1)  # fsdp gathers for the forward and again for the backward
+        return {"reduce_scatter": rs, "all_gather": ag, "total": rs + ag}
+
+    def comm_report(self, reset: bool = True) -> dict:
+        """Exposed communication since the last report (synchronises): ms the compute stream spent waiting, by kind."""
+        out = {"all_gather_wait": 0.0, "reduce_scatter_wait": 0.0, "norm_all_reduce": 0.0}
+        if self._comm_events:
+            torch.cuda.synchronize(self.device)
+            for kind, e0, e1 in self._comm_events:
+                out[kind] = out.get(kind, 0.0) + e0.elapsed_time(e1)
+        out["comm_exposed_ms"] = sum(out.values())
+        out["waits"] = len(self._comm_events)
+        if reset:
+            self._comm_events = []
+        return out
+
     # ---- parameter residency (fsdp) / gather hand-off (zero2) ---------------------------------------------
     def _issue_gather(self, g: int):
         if g < 0 or g >= len(self.groups):
@@ -249,14 +301,18 @@ class ShardedDataParallel:
                 b.resident = True
                 b.ag_work = self._all_gather(b)
 
-    def _ensure(self, g: int):
-        """The parameters of group g are complete on this GPU (for every kernel enqueued on the current stream from now on)."""
+    def _ensure(self, g: int) -> bool:
+        """The parameters of group g are complete on this GPU (for every kernel enqueued on the current stream from now on).
+        Returns whether the current stream was made to wait for a gather."""
         self._issue_gather(g)
+        waited = False
         for bi in self.groups[g]:
             b = self.buckets[bi]
             if b.ag_work is not None:
-                b.ag_work.wait()
+                self._wait(b.ag_work, "all_gather_wait")
                 b.ag_work = None
+                waited = True
+        return waited
 
     def _release(self, g: int):
         for bi in self.groups[g]:
@@ -268,15 +324,50 @@ class ShardedDataParallel:
                 b.flat_param.untyped_storage().resize_(0)
                 b.resident = False
 
+    # ---- gradient staging buffers (fsdp) ---------------------------------------------------------------------
+    def _ensure_grad(self, b: _Bucket):
+        if not b.grad_resident:
+            b.flat_grad.untyped_storage().resize_(b.grad_nbytes)
+            b.flat_grad.zero_()  # parameters without a gradient this step contribute zeros; accumulating producers start at 0
+            b.grad_resident = True
+            b.stale.clear()
+
+    def _free_grad(self, b: _Bucket):
+        """after the bucket's reduce-scatter has been waited for on the current stream (memory reuse is stream-ordered)"""
+        if b.fsdp and b.grad_freeable and b.grad_resident and b.grad_shard is not b.flat_grad:
+            b.flat_grad.untyped_storage().resize_(0)
+            b.grad_resident = False
+            b.stale.clear()
+
+    def _retire_reduce_scatters(self, keep: int):
+        while len(self._rs_inflight) > keep:
+            b = self._rs_inflight.pop(0)
+            if b.rs_work is not None:
+                self._wait(b.rs_work, "reduce_scatter_wait")
+                b.rs_work = None
+            self._free_grad(b)
+
+    def begin_step(self):
+        """Called at the start of every training step: state that an aborted backward (an exception, an evaluation with
+        gradients but no step()) may have left behind does not leak into this step."""
+        self._in_backward = False
+        if self.device.type == "cuda":
+            from . import ops
+
+            ops.reset_backward_state()
+
     # ---- unit hooks: called by the model around every unit's compute ------------------------------------------
-    def pre_forward(self, unit: str):
+    def pre_forward(self, unit: str) -> bool:
+        """Returns True if the current stream had to wait for this unit's parameter gather (other streams that read the
+        parameters must then be ordered behind the current one)."""
         g = self.unit_group.get(unit)
         if g is None:
-            return
-        self._ensure(g)
+            return False
+        waited = self._ensure(g)
         if self.mode == "fsdp" and not self._in_backward:
             for k in range(1, self.prefetch + 1):
                 self._issue_gather(g + k)
+        return waited
 
     def post_forward(self, unit: str, *tensors):
         """Marks the end of a unit's forward; returns `tensors` (wrapped so that the unit's backward announces itself)."""
@@ -292,6 +383,11 @@ class ShardedDataParallel:
     def _pre_backward(self, unit: str):
         self._in_backward = True
         g = self.unit_group[unit]
+        for bi in self.groups[g]:
+            b = self.buckets[bi]
+            if not b.arrived:
+                b.announced = True
+            self._ensure_grad(b)
         self._ensure(g)
         for k in range(1, self.prefetch + 1):
             self._issue_gather(g - k)
@@ -315,6 +411,7 @@ class ShardedDataParallel:
         if p.grad is None:  # the producer returned None: either _on_grad_inplace already ran, or there is no gradient
             return
         b, o = self._where[p]
+        self._ensure_grad(b)
         b.flat_grad[o : o + p.numel()].copy_(p.grad.reshape(-1))
         p.grad = None
         self._arrived(p, b)
@@ -334,6 +431,10 @@ class ShardedDataParallel:
         if b.pending == 0:
             b.rs_work = self._reduce_scatter(b)  # overlaps with the rest of backward
             if b.fsdp:
+                # the staging buffer of the bucket BEFORE this one is given back once its reduce-scatter is done (it has had
+                # a whole bucket of backward compute to finish)
+                self._rs_inflight.append(b)
+                self._retire_reduce_scatters(keep=1)
                 g = self._bucket_group[id(b)]
                 if all(self.buckets[bi].pending == 0 for bi in self.groups[g]):
                     self._release(g)  # nothing in backward reads these parameters any more
@@ -378,6 +479,7 @@ class ShardedDataParallel:
         self._join_streams()  # gradients written by backward nodes on the second stream
         for b in self.buckets:
             if b.pending > 0:  # parameters that received no gradient this step contribute zeros
+                self._ensure_grad(b)
                 for p, o in zip(b.params, b.offsets):
                     if id(p) in b.stale and id(p) not in b.arrived:  # ... not what an earlier step left in their slice
                         b.flat_grad[o : o + p.numel()].zero_()
@@ -385,15 +487,16 @@ class ShardedDataParallel:
                 b.rs_work = self._reduce_scatter(b)
         for b in self.buckets:
             if b.rs_work is not None:
-                b.rs_work.wait()
+                self._wait(b.rs_work, "reduce_scatter_wait")
                 b.rs_work = None
+        self._rs_inflight.clear()
         coef = None
         if self.max_grad_norm is not None:
             self._sumsq.zero_()
             for b in self.buckets:
                 self.ops.sumsq(b.grad_shard, self._sumsq)
             if self.world > 1:
-                dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.group)
+                self._wait(dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.group, async_op=True), "norm_all_reduce")
             self.ops.clip_coef(self._sumsq, self.max_grad_norm, self._coef, self._norm)
             coef = self._coef
         for b in self.buckets:  # forward-use order: the first layers' parameters are complete first
@@ -418,6 +521,12 @@ class ShardedDataParallel:
                         b.stale.add(id(p))
             b.pending = len(b.params)
             b.arrived.clear()
+            if b.fsdp:
+                # a bucket whose backward announced itself before its first gradient (model unit hooks) may drop its staging
+                # buffer between steps from now on; one that did not (plain modules) keeps it: its producers write unannounced
+                b.grad_freeable = b.grad_freeable or b.announced
+                b.announced = False
+                self._free_grad(b)
         self._in_backward = False
         if self.mode == "fsdp":
             self.release_params()
@@ -462,8 +571,9 @@ class ShardedDataParallel:
     def load_state_dict(self, sd, param_order=None):
         """Every rank loads the same dictionary and keeps its slices — any world size, any bucket layout.  Entries are matched
         by parameter name (`param_names` in the file, else `param_order`); a plain torch AdamW state dict (the reference's
-        optimizer.pt: index = position in model.parameters(), bf16 moments, no master) therefore loads too: moments are
-        widened to f32 and the master copies are taken from the current parameters.  The model weights must already be in
+        optimizer.pt: index = position in model.parameters(), bf16 moments, no master, no entry for parameters that never
+        received a gradient) therefore loads too: moments are widened to f32, master copies missing from the file are taken
+        from the current parameters, parameters without an entry start from zero moments.  The model weights must already be in
         place (load them first): the fsdp shards are re-read from them."""
         pnames = sd.get("param_names", param_order)
         if pnames is None:
@@ -472,29 +582,44 @@ class ShardedDataParallel:
         by_name = {pnames[i]: ent for i, ent in state.items()}
         steps = [float(s["step"]) for s in state.values() if "step" in s]
         self.step_count = int(sd.get("step", max(steps) if steps else 0))
-        need_master = False
+        # torch.optim.AdamW only holds state for parameters that have received a gradient: in the reference's optimizer.pt the
+        # last layer's prefix o_proj / MLP / post-attention norm and language_model.norm (dead values) have no entry.
+        # A missing entry = "never updated": zero moments, master copy = the current parameter.  Master copies are adopted per
+        # parameter — an entry without `master` (torch-shaped file) does not discard the f32 masters other entries carry.
+        from_params: list[tuple[_Bucket, int, int]] = []  # (bucket, lo, hi) slices whose master comes from the parameters
+        absent = []
         for b in self.buckets:
             for p, o, n in zip(b.params, b.offsets, b.names):
                 ent = by_name.get(n)
-                if ent is None:
-                    raise KeyError(f"optimizer state has no entry for parameter {n}")
                 lo, hi = max(o, b.lo), min(o + p.numel(), b.lo + b.shard)
+                if ent is None:
+                    absent.append(n)
+                    ent = {}
                 for key in ("exp_avg", "exp_avg_sq", "master"):
                     if key not in ent:
-                        need_master = True
+                        if lo < hi:
+                            if key == "master":
+                                from_params.append((b, lo, hi))
+                            else:
+                                getattr(b, key)[lo - b.lo : hi - b.lo].zero_()
                         continue
                     if ent[key].numel() != p.numel():
                         raise ValueError(f"optimizer state of {n}: {tuple(ent[key].shape)} vs parameter {tuple(p.shape)}")
                     if lo < hi:
                         getattr(b, key)[lo - b.lo : hi - b.lo].copy_(ent[key].reshape(-1)[lo - o : hi - o].to(F32))
+        if absent:
+            import logging
+
+            logging.getLogger("kai0_amd").warning(
+                "optimizer state has no entry for %d parameter(s) (never updated when it was written; zero moments assumed): %s%s",
+                len(absent), ", ".join(absent[:4]), " ..." if len(absent) > 4 else "")  # fmt: skip
         self.wait_params()
         self._check_views()
+        for b, lo, hi in from_params:  # the alignment padding between parameters keeps whatever the master held (zeros)
+            b.master[lo - b.lo : hi - b.lo].copy_(b.flat_param[lo:hi])
         for b in self.buckets:
-            sl = b.flat_param[b.lo : b.lo + b.shard]
-            if need_master:  # no master copies in the file: adopt the current parameters
-                b.master.copy_(sl)
             if b.fsdp:
-                b.param_shard.copy_(sl)
+                b.param_shard.copy_(b.flat_param[b.lo : b.lo + b.shard])
         if self.mode == "fsdp":
             self.release_params()
 

@@ -104,10 +104,10 @@ def test_fulldepth_loss_and_gradients_match_oracle(fd):
     table, bad = [], []
     for n, p in o32.named_parameters():
         g = p.grad
-        if g is None:
-            assert gm[n] is None or float(gm[n].abs().max()) == 0.0, f"{n} must not receive a gradient"
+        if g is None:  # (the oracle's tied lm_head is a separate, unused tensor after to_empty: not a parameter of the HIP model)
+            assert gm.get(n) is None or float(gm[n].abs().max()) == 0.0, f"{n} must not receive a gradient"
             continue
-        assert gm[n] is not None, f"no gradient for {n}"
+        assert gm.get(n) is not None, f"no gradient for {n}"
         if float(g.norm()) < 1e-9:
             assert float(gm[n].float().norm()) < 1e-5, n
             continue
