@@ -195,7 +195,19 @@ def cpu_baseline(batch: int = 32):
     opt.step()
     t_opt = (time.time() - t0) * n_all / n_sub
     step_s = batch * t_fb + t_opt
+    # the action chunk on the same host cores: oracle `sample_actions`, B = 1, prefix pass with KV cache + 10
+    # Euler steps, fp32, no autograd; one timed call (the forward/backward passes above already paged the weights in)
+    del opt
+    model.zero_grad(set_to_none=True)
+    noise1 = torch.randn(1, cfg.action_horizon, cfg.action_dim, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        t0 = time.time()
+        model.sample_actions(obs, noise1, num_steps=10)
+        t_chunk = time.time() - t0
+    infer = {"value": t_chunk * 1e3, "unit": "ms per action chunk (B = 1, 10 steps)", "cores": cores, "kind": "port",
+             "sample": f"fp32 oracle `sample_actions` at full depth and width, one call after the weights were paged in: {t_chunk:.2f} s"}  # fmt: skip
     return {
+        "inference": infer,
         "value": batch / step_s,
         "unit": "samples/s",
         "cores": cores,
@@ -359,6 +371,45 @@ def main():
         if timer is not None:
             timer.uninstall()
         _model.set_expert_stream(dual_was)
+    # N > 1: what the collectives cost the compute stream.  Two further steps with the engine's wait bookkeeping on (events around
+    # every place where the compute stream waits for a gather / reduce-scatter / the norm all-reduce, kai0_amd.sharded): per rank,
+    # the ms per step the chip sat in those waits, i.e. the communication that overlap did NOT hide.  Outside the timed region for the
+    # same reason as the GEMM timing.
+    comm = None
+    if world > 1 or os.environ.get("KAI0_FORCE_COLLECTIVES") == "1":
+        eng = trainer.engine
+        eng.comm_profile = True
+        eng.comm_report()
+        barrier()
+        tc0 = time.perf_counter()
+        for _ in range(timer_steps):
+            trainer.train_step(obs, actions)
+        barrier()
+        tc = (time.perf_counter() - tc0) / timer_steps * 1e3
+        rep = eng.comm_report()
+        eng.comm_profile = False
+        mine = torch.tensor([rep["comm_exposed_ms"] / timer_steps, rep["all_gather_wait"] / timer_steps,
+                             rep["reduce_scatter_wait"] / timer_steps, rep["norm_all_reduce"] / timer_steps, tc],
+                            dtype=torch.float64, device=device)  # fmt: skip
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        by = eng.comm_bytes_per_step()
+        comm = {
+            "mode": eng.mode, "buckets": len(eng.buckets), "bucket_mb": max(b.numel * b.flat_param.element_size() for b in eng.buckets) / 2**20,
+            "comm_exposed_ms_per_rank": [float(t[0]) for t in allr],
+            "all_gather_wait_ms_per_rank": [float(t[1]) for t in allr],
+            "reduce_scatter_wait_ms_per_rank": [float(t[2]) for t in allr],
+            "norm_all_reduce_ms_per_rank": [float(t[3]) for t in allr],
+            "ms_per_step_while_measured": max(float(t[4]) for t in allr),
+            "bytes_per_rank_per_step": by,
+            "xgmi_gbs_if_fully_overlapped": by["total"] / 1e9 / (max(float(t[4]) for t in allr) / 1e3) if by["total"] else 0.0,
+            "rccl_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE",
+                                                    "RCCL_MSCCLPP_ENABLE") if k in os.environ},
+            "measured": f"events on the compute stream around every collective wait, {timer_steps} steps after the timed region",
+        }  # fmt: skip
     # Extra (not the headline value): the same step with the prompt cut to the longest valid prompt of the batch
     # (model.trim_prompt_padding: the 200 prompt slots carry 64-128 valid tokens here; padded slots are invisible keys and unread
     # rows, loss and gradients unchanged beyond summation order — tests/test_model_gpu.py).  The headline number above computes
@@ -412,7 +463,8 @@ def main():
                 "workload": "pi0.5 full fine-tune bf16, batch 32 per MI355X, 3-cam 224x224 (BASELINE.json configs[1])",
                 "global_batch": B * world,
                 "seq_len": 968 + 50,
-                "parallelism": f"dp{world}" + ("" if world == 1 else " (sharded optimizer/grads, RCCL reduce-scatter + all-gather)"),
+                "parallelism": f"dp{world}" + ("" if world == 1 else f" ({trainer.engine.mode}: sharded optimizer/grads"
+                                                + ("/params" if trainer.engine.mode == "fsdp" else "") + ", RCCL reduce-scatter + all-gather)"),
                 "params_stored": 3.617e9,
                 "final_loss": float(loss),
             },
@@ -451,6 +503,8 @@ def main():
             if os.environ.get("KAI0_GEMM_BREAKDOWN"):
                 os.makedirs("gpurun_out", exist_ok=True)
                 json.dump(timer.breakdown(), open("gpurun_out/gemm_breakdown.json", "w"), indent=0)
+        if comm is not None:
+            out["comm"] = comm
         if trimmed is not None:
             out["trimmed_prompt"] = trimmed
         if world == 1 and not args.no_latency:
@@ -460,6 +514,9 @@ def main():
             out["p50_action_chunk_ms"] = out["inference"]["p50_ms"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
+            cb_inf = out["cpu_baseline"].pop("inference", None)
+            if cb_inf is not None and "inference" in out:
+                out["inference"]["cpu_baseline"] = cb_inf
         try:  # whatever native libraries still hold in C stdio buffers goes out first: the JSON line must be the last one
             import ctypes
 

@@ -116,6 +116,14 @@ typedef struct kai0_gemm_desc {
      * row's <dP, P>.  dP is taken from the f32 accumulator: it is never rounded and never written. */
     const float* rowvec;
     int64_t rv_s1, rv_s2, rv_ld;
+    /* act 6 — the Gemma MLP's gate and up projections with GeGLU as ONE GEMM (modeling_gemma.py:113-126: `act_fn(gate_proj(x)) *
+     * up_proj(x)`): B = gate_proj.weight, B2 = up_proj.weight (both [N][ldb] bf16, K-contiguous), N = the MLP width.  The kernel
+     * stages the two weights interleaved in 32-row groups, so every wave holds gate and up pre-activations of the same output
+     * columns and combines them in registers: C = h = bf16(bf16(gelu_tanh(g)) * u) with g = bf16(x Wg^T), u = bf16(x Wu^T) — the
+     * rounding points of act 2 — and, when set, pre_out = g and pre_out2 = u (what the backward needs), all addressed like C.
+     * Against gate GEMM + up GEMM with act 2: one launch, no read-back of g in the epilogue, and in inference no g / u writes. */
+    const void* B2;
+    void* pre_out2;
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);

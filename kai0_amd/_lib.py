@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("aux1", c_p), ("aux2", c_p),
         ("nseg", C.c_int32), ("_pad2", C.c_int32), ("seg", GemmSeg * 3),
         ("rowvec", c_p), ("rv_s1", c_i64), ("rv_s2", c_i64), ("rv_ld", c_i64),
+        ("B2", c_p), ("pre_out2", c_p),
     ]  # fmt: skip
 
 

@@ -71,6 +71,12 @@ struct GemmArgs {
     int seg_begin[3];
     float* ws;             // split-K workspace [batch*split_k][M][N] f32
     int split_k, k_chunk;  // split-K: blockIdx.y = z * split_k + s, split s owns k in [s*k_chunk, min(K, (s+1)*k_chunk))
+    // act 6 (GeGLU pair): the B operand is TWO weights, gate = B and up = B2, interleaved in 32-row groups along the tile's N
+    // axis (logical column 64 c + j: j < 32 -> gate row 32 c + j, else up row 32 c + j - 32), so that every wave's 64-column
+    // sub-tile holds gate AND up of the same 32 output columns and GeGLU needs no operand from memory.  N is the LOGICAL width
+    // (2 x output columns).
+    const bf16_t* B2;
+    bf16_t* pre_out2;
 };
 
 // LDS-DMA through a raw buffer descriptor: 16 B per lane from base + voff (bytes) to lds_dst + lane*16.  An offset at
@@ -298,6 +304,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const int m0 = tile_m * TBM, n0 = tile_n * TBN;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)OOB, 0x00020000);
+    const bool pair = p.act == 6;  // (host: A and B K-contiguous, one batch entry, no split-K)
+    const __amdgpu_buffer_rsrc_t b2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(pair ? p.B2 : Bb), 0, (int)OOB, 0x00020000);
 
     // ---- staging source addresses ----------------------------------------------------------------
     // K-contiguous tile [rows][64 k] (128-B rows): DMA piece q covers rows q*8..q*8+7; lane -> row q*8+(lane>>3),
@@ -327,8 +335,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     if constexpr (B_KC) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int R = n0 + (wave * NB + j) * KC_RPP + lane / KC_CPR;
-            b_off[j] = R < p.N ? (uint32_t)((p.bmap(R) * p.ldb + kc_chunk) * 2) : OOB;
+            const int rt = (wave * NB + j) * KC_RPP + lane / KC_CPR;  // row of the B tile
+            int R = n0 + rt;
+            bool ok = R < p.N;
+            if (pair) {  // 32-row groups alternate gate / up; both index the same weight rows (n0 / 2 + 32 (rt / 64) + rt % 32)
+                R = (n0 >> 1) + ((rt >> 6) << 5) + (rt & 31);
+                ok = R < (p.N >> 1);
+            }
+            b_off[j] = ok ? (uint32_t)((p.bmap(R) * p.ldb + kc_chunk) * 2) : OOB;
         }
     } else {
 #pragma unroll
@@ -366,7 +380,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 const int kr = k0 + (wave * NB + j) * B_RPP + lane / B_LPR;
                 off = kr < kend ? b_off[j] + (uint32_t)p.bmap(kr) * ldb2 : OOB;
             }
-            glds16(b_rsrc, off, sb + j * 1024);
+            // pair: the piece's 8 tile rows lie in one 32-row group -> gate or up weight, wave-uniform
+            glds16((B_KC && BK == 64 && pair && (((wave * NB + j) * KC_RPP) & 32)) ? b2_rsrc : b_rsrc, off, sb + j * 1024);
         }
     };
 
@@ -527,10 +542,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                     ha_off[x] = col < p.M ? (uint32_t)(col * 2) : OOB;
                 }
                 if constexpr (B_KC) {
-                    const int rb = (q >> 2) * 64 + h * 32 + (q & 3) * 8, Rb = n0 + rb + (lane >> 3);
+                    const int rb = (q >> 2) * 64 + h * 32 + (q & 3) * 8;
+                    int Rb = n0 + rb + (lane >> 3);
+                    bool ok = Rb < p.N;
+                    if (pair) {  // half-operand B_h = 32-column group h of every wave: h = 0 gate rows, h = 1 up rows (issue_half)
+                        Rb = (n0 >> 1) + (q >> 2) * 32 + (q & 3) * 8 + (lane >> 3);
+                        ok = Rb < (p.N >> 1);
+                    }
                     hb_lds[x] = rb * 128;
                     hb_kr[x] = 0;
-                    hb_off[x] = Rb < p.N ? (uint32_t)((p.bmap(Rb) * p.ldb + kc_chunk) * 2) : OOB;
+                    hb_off[x] = ok ? (uint32_t)((p.bmap(Rb) * p.ldb + kc_chunk) * 2) : OOB;
                 } else {
                     const int r = q * 4 + (lane >> 4), key = (r & 3) | (((r >> 3) & 1) << 2);
                     const int col = n0 + h * 128 + (((lane & 15) ^ (key << 1)) * 8);
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                     if (kr < kend && o != OOB) off = o + (uint32_t)(isb ? p.bmap(kr) : p.amap(kr)) * (isb ? ldb2 : lda2);
                 }
                 if (p.ablate == 1) off = OOB;
-                glds16(isb ? b_rsrc : a_rsrc, off, base + (isb ? hb_lds[x] : ha_lds[x]));
+                glds16(isb ? ((pair && h == 1) ? b2_rsrc : b_rsrc) : a_rsrc, off, base + (isb ? hb_lds[x] : ha_lds[x]));
             }
         };
         issue_half(false, 0, 0);
@@ -757,6 +778,52 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                             (p.act != 3 || p.pre_out != nullptr);
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
+        if (pair) {
+            // GeGLU in registers: slab columns [0, 32) = gate, [32, 64) = up of the wave's 32 output columns n0/2 + wn*32 + ..;
+            // each lane takes 8 of them for one row (16 rows per pass).  Rounding points of act 2: g = bf16(acc), u = bf16(acc),
+            // h = bf16(bf16(gelu_tanh(g)) * u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int ocol = (n0 >> 1) + wn * 32 + (lane & 3) * 8;
+            const bool ocol_ok = ocol < (p.N >> 1);
+            bf16_t* cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int lr = it * 16 + (lane >> 2);
+                const int row = row_base(h) + lr;
+                const float* sp = slab + lr * 64 + (lane & 3) * 8;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp), g1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(sp + 32), u1 = *reinterpret_cast<const f32x4*>(sp + 36);
+                if (row >= p.M || !ocol_ok) continue;
+                const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                const float uv[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                bf16x8 gb, ub, hb;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 gr = rbf2(f32x2{gv[e], gv[e + 1]}), ur = rbf2(f32x2{uv[e], uv[e + 1]});
+                    const f32x2 hv = rbf2(gelu_tanh2(gr)) * ur;
+                    gb[e] = f2bf(gr[0]);
+                    gb[e + 1] = f2bf(gr[1]);
+                    ub[e] = f2bf(ur[0]);
+                    ub[e + 1] = f2bf(ur[1]);
+                    hb[e] = f2bf(hv[0]);
+                    hb[e + 1] = f2bf(hv[1]);
+                }
+                const int64_t o = cz + p.cmap(row) * p.ldc + ocol;
+                *reinterpret_cast<bf16x8*>(cb + o) = hb;
+                if (p.pre_out != nullptr) *reinterpret_cast<bf16x8*>(p.pre_out + o) = gb;
+                if (p.pre_out2 != nullptr) *reinterpret_cast<bf16x8*>(p.pre_out2 + o) = ub;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         if (fused_fast) {
             bf16x8 s0[8], s1[8];
             float ds[8];
@@ -902,7 +969,7 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
     constexpr int LDS = NS * (TBM + TBN) * BKT * 2;
     p.tiles_m = (d->M + TBM - 1) / TBM;
-    p.tiles_n = (d->N + TBN - 1) / TBN;
+    p.tiles_n = (p.N + TBN - 1) / TBN;
     dim3 grid(p.tiles_m * p.tiles_n, batch * p.split_k, 1), block(WM * WN * 64, 1, 1);
 #define KAI0_LAUNCH(AK, BK_)                                                                                      \
     do {                                                                                                          \
@@ -960,7 +1027,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
-    KAI0_REQUIRE(d->act >= 0 && d->act <= 5, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act >= 0 && d->act <= 6, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act != 6 || (d->B2 && d->a_kc && d->b_kc && d->batch <= 1 && d->split_k <= 1 && !d->out_f32 && !d->accumulate &&
+                                 d->nseg == 0 && !d->bias && !d->gate && !d->residual && (d->scale == 0.0f || d->scale == 1.0f) &&
+                                 (d->N % 32) == 0 && d->b_rpb == 0 && ((uintptr_t)d->B2 % 16) == 0),
+                 "kai0_gemm_bf16: act=6 (GeGLU pair) needs B2 = up weight, K-contiguous operands, N %% 32 == 0, one batch entry, a "
+                 "plain bf16 output");
     KAI0_REQUIRE(d->act != 5 || (d->aux1 && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
                  "kai0_gemm_bf16: act=5 (fused GELU backward) needs aux1 = pre-activation, plain bf16 output");
     KAI0_REQUIRE(d->act != 4 || (d->aux1 && d->rowvec && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
@@ -993,7 +1065,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.A = (const bf16_t*)d->A;
     p.B = (const bf16_t*)d->B;
     p.C = d->C;
-    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.M = d->M; p.N = d->act == 6 ? 2 * d->N : d->N; p.K = d->K;  // act 6: logical width = gate | up interleaved
+    p.B2 = (const bf16_t*)d->B2;
+    p.pre_out2 = (bf16_t*)d->pre_out2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
     p.sA1 = d->sA1; p.sA2 = d->sA2; p.sB1 = d->sB1; p.sB2 = d->sB2; p.sC1 = d->sC1; p.sC2 = d->sC2;
@@ -1033,7 +1107,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // tile configuration: 256x256 (1 block of 8 waves per CU, half the staged bytes per FLOP) when the problem gives
     // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
     const int forced = g_gemm_cfg;
-    const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch * (split > 1 ? split : 1);
+    const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((p.N + 255) / 256) * batch * (split > 1 ? split : 1);
     const bool big = forced ? forced >= 4 : (big_tiles >= 160 && d->K >= 256);
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -1041,7 +1115,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // layouts (their load slot is longer than the MFMA slot), so only NT uses it
     const bool pp = forced ? forced == 5 : (d->a_kc && d->b_kc);
     // few 128x128 tiles (at most one block per CU): nothing else hides the load latency -> 4-stage pipeline
-    const int64_t small_blocks = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch * (split > 1 ? split : 1);
+    const int64_t small_blocks = (int64_t)((d->M + 127) / 128) * ((p.N + 127) / 128) * batch * (split > 1 ? split : 1);
     const bool deep = forced ? forced == 2 : (small_blocks <= 256 && p.k_chunk >= 256);
     // forced: 4 = 256x256 plain, 5 = 256x256 two-buffer ping-pong (all layouts), 6 = ring for NT only, 7 = ring for all
     // measured (MLP shapes, random data): the ring wins +21 % for the transpose-read layout (TN wgrads: 512-B source rows,

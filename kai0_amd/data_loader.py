@@ -100,6 +100,7 @@ class TorchDataLoader:
         if len(dataset) < local_batch_size:
             raise ValueError(f"Local batch size ({local_batch_size}) is larger than the dataset size ({len(dataset)}).")
         self._num_batches = num_batches
+        self._skip = 0
         generator = torch.Generator()
         generator.manual_seed(seed)
         self._data_loader = torch.utils.data.DataLoader(
@@ -111,10 +112,20 @@ class TorchDataLoader:
     def torch_loader(self) -> torch.utils.data.DataLoader:
         return self._data_loader
 
+    def skip_batches(self, n: int) -> None:
+        """Resume support: the next iteration discards its first `n` batches, i.e. continues the (seeded, hence reproducible)
+        batch stream where a run that had consumed `n` batches stopped.  The skipped batches are still loaded — the order is
+        whatever the sampler and the loader's generator produce, replayed, not re-derived."""
+        self._skip = max(0, int(n))
+
     def __iter__(self):
         produced = 0
+        skip, self._skip = self._skip, 0
         while True:  # a new pass over the dataset whenever the previous one is exhausted
             for batch in self._data_loader:
+                if skip > 0:
+                    skip -= 1
+                    continue
                 if self._num_batches is not None and produced >= self._num_batches:
                     return
                 produced += 1
@@ -131,6 +142,9 @@ class DataLoaderImpl:
 
     def data_config(self):
         return self._data_config
+
+    def skip_batches(self, n: int) -> None:
+        self._data_loader.skip_batches(n)
 
     def __iter__(self):
         for batch in self._data_loader:

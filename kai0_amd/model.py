@@ -18,6 +18,8 @@ Layout choices (MI355X-first, not a translation of the HF modules):
 
 from __future__ import annotations
 
+import dataclasses
+
 import contextlib
 import os
 
@@ -302,6 +304,12 @@ class PaliGemmaWithExpertModel(nn.Module):
             raise NotImplementedError("adaRMS on the PaliGemma tower is not part of pi0.5")
         self.vlm_cfg, self.exp_cfg = vlm_config, action_expert_config
         self.siglip_cfg = siglip or SiglipConfig()
+        if self.siglip_cfg.projection_dim != vlm_config.width:
+            # The image tokens join the prompt tokens in ONE prefix sequence: the projector must end at the PaliGemma width.  The
+            # reference's torch model hard-codes 2048 (gemma_pytorch.py:39: right for gemma_2b, a shape error in its torch.cat for
+            # the "dummy" variants of debug / debug_pi05); its JAX model sizes the head by the tower (pi0.py:83
+            # `num_classes=paligemma_config.width`), which is what is done here instead of failing.
+            self.siglip_cfg = dataclasses.replace(self.siglip_cfg, projection_dim=vlm_config.width)
         self.paligemma = PaliGemmaForConditionalGeneration(vlm_config, vocab, self.siglip_cfg)
         self.gemma_expert = GemmaForCausalLM(action_expert_config, vocab, use_adarms[1])
         self.remat = False
@@ -735,6 +743,9 @@ class PrefixAssembleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, lang, B: int, ncam: int, n_img: int, T: int):
         D = feats.shape[1]
+        if lang.shape[-1] != D or feats.shape[0] != ncam * B * n_img or lang.numel() != B * T * D:
+            raise ValueError(f"prefix assembly: image tokens {tuple(feats.shape)} and prompt tokens {tuple(lang.shape)} do not form "
+                             f"one [B={B}, {ncam} x {n_img} + {T}, D] sequence (projector width must equal the PaliGemma width)")
         P = ncam * n_img + T
         out = torch.empty((B * P, D), dtype=BF16, device=feats.device)
         for c in range(ncam):

@@ -55,6 +55,7 @@ def gemm(
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
     aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None, rowvec=None, rv=(0, 0, 1),
+    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -89,6 +90,11 @@ def gemm(
     d.out_f32 = int(out_f32)
     d.pre_out = _p(pre_out)
     d.aux1, d.aux2 = _p(aux1), _p(aux2)
+    if B2 is not None:  # act 6: gate (B) | up (B2) weights of the GeGLU pair GEMM
+        if B2.dtype != BF16 or not B2.is_cuda:
+            raise TypeError("gemm: B2 must be a bf16 HIP tensor")
+        d.B2 = B2.data_ptr()
+    d.pre_out2 = _p(pre_out2)
     if gate is not None:
         d.gate = gate.data_ptr()
         d.gate_rpb = gate_rpb
@@ -832,6 +838,15 @@ def geglu(g, u):
     return GegluFn.apply(g, u)
 
 
+_GEGLU_PAIR = os.environ.get("KAI0_GEGLU_PAIR", "1") != "0"  # 0: gate GEMM + up GEMM with the act-2 epilogue (A/B, tests)
+
+
+def set_geglu_pair(on: bool) -> bool:
+    global _GEGLU_PAIR
+    old, _GEGLU_PAIR = _GEGLU_PAIR, bool(on)
+    return old
+
+
 class GegluMlpFn(torch.autograd.Function):
     """Gemma MLP `down(gelu_tanh(gate(x)) * up(x)) (+ residual)` (modeling_gemma.py:113-126) as three GEMMs with the
     GeGLU fused into epilogues: forward in the up-projection GEMM (reads g, writes u and h), backward in the
@@ -843,10 +858,15 @@ class GegluMlpFn(torch.autograd.Function):
         _chk(x, BF16, "geglu_mlp.x")
         M, D = x.shape
         F = wg.shape[0]
-        g = linear_fwd(x, wg)
         u = torch.empty((M, F), dtype=BF16, device=x.device)
         h = torch.empty((M, F), dtype=BF16, device=x.device)
-        gemm(x, wu, h, M=M, N=F, K=D, lda=D, ldb=D, ldc=F, act=2, pre_out=u, aux1=g, split_k=1)
+        if _GEGLU_PAIR and F % 32 == 0:
+            # gate | up as ONE GEMM over the two weights, GeGLU in registers (act 6): no read-back of g in an epilogue
+            g = torch.empty((M, F), dtype=BF16, device=x.device)
+            gemm(x, wg, h, M=M, N=F, K=D, lda=D, ldb=D, ldc=F, act=6, B2=wu, pre_out=g, pre_out2=u)
+        else:
+            g = linear_fwd(x, wg)
+            gemm(x, wu, h, M=M, N=F, K=D, lda=D, ldb=D, ldc=F, act=2, pre_out=u, aux1=g, split_k=1)
         out = linear_fwd(h, wd, residual=residual)
         ctx.save_for_backward(x, wg, wu, wd, g, u, h)
         ctx.has_res = residual is not None

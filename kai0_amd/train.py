@@ -105,13 +105,16 @@ class Trainer:
         tmp = os.path.join(checkpoint_dir, f"tmp_{step}")
         self.engine.wait_params()
         opt_sd = self.engine.state_dict(self._param_order)
+        rng = _gather_rng_states(self.world, self.engine.device)
         if self.rank == 0:
             if os.path.exists(tmp):
                 shutil.rmtree(tmp)
             os.makedirs(tmp, exist_ok=True)
             save_model_safetensors(self.model, os.path.join(tmp, "model.safetensors"))
             torch.save(opt_sd, os.path.join(tmp, "optimizer.pt"))
-            meta = {"global_step": step, "world_size": self.world, "timestamp": time.time()}
+            # (not in the reference's metadata) the ranks' RNG states: with them and `skip_batches` a resumed run draws the same
+            # noise / time / augmentation and sees the same batches as the run that was interrupted
+            meta = {"global_step": step, "world_size": self.world, "timestamp": time.time(), "rng_state": rng}
             if config is not None:
                 meta["config"] = _plain(dataclasses.asdict(config) if dataclasses.is_dataclass(config) else config)
             torch.save(meta, os.path.join(tmp, "metadata.pt"))
@@ -140,10 +143,34 @@ class Trainer:
         # tensors, numbers, lists and strings only: no pickle execution from a checkpoint directory (ADVICE r2)
         opt = torch.load(os.path.join(d, "optimizer.pt"), map_location="cpu", weights_only=True)
         self.engine.load_state_dict(opt, self._param_order)
-        self.global_step = int(torch.load(os.path.join(d, "metadata.pt"), map_location="cpu", weights_only=True).get("global_step", step))
+        meta = torch.load(os.path.join(d, "metadata.pt"), map_location="cpu", weights_only=True)
+        self.global_step = int(meta.get("global_step", step))
+        self.resumed_rng_state = meta.get("rng_state")  # train_loop restores it when the world size is the one that wrote it
         if getattr(self.model, "_engine", None) is not None:
             self.model.invalidate_inference_engine()
         return self.global_step
+
+
+def _gather_rng_states(world: int, device) -> list:
+    """[{cpu, cuda}] per rank (uint8 tensors); collective when world > 1."""
+    mine = {"cpu": torch.get_rng_state()}
+    if torch.device(device).type == "cuda":
+        mine["cuda"] = torch.cuda.get_rng_state(device)
+    if world <= 1:
+        return [mine]
+    box = [None] * world
+    torch.distributed.all_gather_object(box, mine)
+    return box
+
+
+def _restore_rng_state(states, world: int, rank: int, device) -> bool:
+    if not states or len(states) != world:
+        return False
+    st = states[rank]
+    torch.set_rng_state(st["cpu"])
+    if "cuda" in st and torch.device(device).type == "cuda":
+        torch.cuda.set_rng_state(st["cuda"], device)
+    return True
 
 
 def _plain(x):
@@ -238,15 +265,14 @@ def train_loop(config, *, device=None, shard_ops=None, model=None, log=None):
                       weight_decay=opt.weight_decay, clip_norm=opt.clip_gradient_norm, shard_ops=shard_ops)  # fmt: skip
     if resuming:
         step = trainer.load_checkpoint(str(ckpt_dir))
-        say(f"Resumed training from step {step}")
+        exact = _restore_rng_state(getattr(trainer, "resumed_rng_state", None), world, rank, device)
+        loader.skip_batches(step)  # every step consumed one batch of the seeded stream
+        say(f"Resumed training from step {step}" + ("" if exact else " (no RNG state for this world size: noise / augmentation restart from the seed)"))
     say(f"world_size={world} batch_size={config.batch_size} (per GPU {config.batch_size // world}) num_train_steps={config.num_train_steps} "
         f"mode={trainer.engine.mode} lr: warmup={sch.warmup_steps} peak={sch.peak_lr:.2e} decay_steps={sch.decay_steps} end={sch.decay_lr:.2e}")  # fmt: skip
 
     records, pending, t0 = [], [], time.time()
     while trainer.global_step < config.num_train_steps:
-        sampler = getattr(getattr(loader._data_loader, "torch_loader", None), "sampler", None)
-        if hasattr(sampler, "set_epoch"):
-            sampler.set_epoch(trainer.global_step)  # a new shuffle per pass (train_pytorch.py:519-521)
         produced = False
         for observation, actions in DeviceFeeder(loader, device):
             if trainer.global_step >= config.num_train_steps:

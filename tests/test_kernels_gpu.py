@@ -377,7 +377,7 @@ def test_geglu_and_gated_residual(ops):
     assert_close_bf16(gate.grad, gtr.grad, what="gated dgate", tol=1e-2)
 
 
-@pytest.mark.parametrize("M,D,Fd", [(200, 64, 136), (4352, 256, 520)])
+@pytest.mark.parametrize("M,D,Fd", [(200, 64, 136), (4352, 256, 520), (300, 64, 128)])
 def test_geglu_mlp_fused(ops, M, D, Fd):
     x = rnd(M, D, seed=1).requires_grad_(True)
     wg, wu = (rnd(Fd, D, seed=s, scale=0.1).requires_grad_(True) for s in (2, 3))
@@ -394,6 +394,29 @@ def test_geglu_mlp_fused(ops, M, D, Fd):
     for n, t, r in zip(("dx", "dwg", "dwu", "dwd"), (x, wg, wu, wd), ref_in):
         assert rel_err(t.grad, r.grad) < 1.5e-2, f"{n}: {rel_err(t.grad, r.grad):.3e}"
     assert torch.equal(res.grad, dy)
+
+
+@pytest.mark.parametrize("M,D,Fd", [(200, 64, 128), (4352, 256, 512), (968, 2048, 16384), (4100, 2048, 16384), (50, 1024, 4096)])
+def test_gemm_geglu_pair_equals_gate_gemm_plus_up_gemm(ops, M, D, Fd):
+    """act 6 (gate | up as one GEMM over two weights, GeGLU in registers) against the two-launch form it replaces (gate GEMM, then
+    up GEMM with the act-2 epilogue): h, g and u bit for bit — in the 128x128 and the 256x256 quadrant configurations, ragged M,
+    with and without the pre-activation outputs; and against an fp32 reference of the op."""
+    x = rnd(M, D, seed=1)
+    wg, wu = rnd(Fd, D, seed=2, scale=0.05), rnd(Fd, D, seed=3, scale=0.05)
+    g_ref = ops.linear_fwd(x, wg)
+    u_ref, h_ref = torch.empty_like(g_ref), torch.empty_like(g_ref)
+    ops.gemm(x, wu, h_ref, M=M, N=Fd, K=D, lda=D, ldb=D, ldc=Fd, act=2, pre_out=u_ref, aux1=g_ref)
+    g, u, h = (torch.full_like(g_ref, float("nan")) for _ in range(3))
+    ops.gemm(x, wg, h, M=M, N=Fd, K=D, lda=D, ldb=D, ldc=Fd, act=6, B2=wu, pre_out=g, pre_out2=u)
+    assert torch.equal(g, g_ref) and torch.equal(u, u_ref) and torch.equal(h, h_ref)
+    h2 = torch.full_like(h_ref, float("nan"))
+    ops.gemm(x, wg, h2, M=M, N=Fd, K=D, lda=D, ldb=D, ldc=Fd, act=6, B2=wu)  # inference: only h
+    assert torch.equal(h2, h_ref)
+    xf = x.float()
+    ref = torch.nn.functional.gelu((xf @ wg.float().t()).bfloat16().float(), approximate="tanh") * (xf @ wu.float().t()).bfloat16().float()
+    assert_close_bf16(h, ref, tol=1.2e-2, what="geglu pair h")
+    with pytest.raises(Exception, match="act=6"):
+        ops.gemm(x, wg, h2, M=M, N=Fd, K=D, lda=D, ldb=D, ldc=Fd, act=6)  # no B2
 
 
 @pytest.mark.parametrize("M,D,Fd", [(200, 64, 136), (4352, 256, 520), (4100, 1152, 4304)])

@@ -482,3 +482,28 @@ def test_trimmed_prompt_padding_gives_the_same_loss_and_gradients(pair):
     assert worst < 2e-2
     assert set(res[True][1]) == set(res[False][1])
     m.zero_grad(set_to_none=True)
+
+
+@pytest.mark.timeout(600)
+def test_train_loop_debug_pi05_resume_is_exact(tmp_path):
+    """`train_loop(get_config("debug_pi05"))` over the HIP model (scripts/train_pytorch.py:309-633): 6 steps in one
+    go, against the same run stopped after 4 steps and resumed to 6 from its checkpoint — steps 4 and 5 must log the same loss,
+    learning rate and gradient norm (weights, f32 master copies, moments, RNG state and the batch stream all continue)."""
+    import dataclasses as dc
+
+    from kai0_amd import training_config as tc
+    from kai0_amd.train import train_loop
+
+    base = dc.replace(tc.get_config("debug_pi05"), checkpoint_base_dir=str(tmp_path / "ckpt"), assets_base_dir=str(tmp_path / "assets"),
+                      num_workers=0, num_train_steps=6, log_interval=1, save_interval=100,
+                      lr_schedule=tc.CosineDecaySchedule(warmup_steps=2, peak_lr=1e-3, decay_steps=10, decay_lr=1e-4))  # fmt: skip
+    full = train_loop(dc.replace(base, exp_name="full", overwrite=True))
+    assert [r["step"] for r in full] == list(range(6)) and all(r["loss"] == r["loss"] for r in full)
+    assert sorted(os.listdir(tmp_path / "ckpt" / "debug_pi05" / "full" / "6")) == ["metadata.pt", "model.safetensors", "optimizer.pt"]
+    part = train_loop(dc.replace(base, exp_name="cut", num_train_steps=4, overwrite=True))
+    assert [r["loss"] for r in part] == [r["loss"] for r in full[:4]]  # the step itself is deterministic
+    rest = train_loop(dc.replace(base, exp_name="cut", overwrite=False, resume=True))
+    assert [r["step"] for r in rest] == [4, 5]
+    for a, b in zip(rest, full[4:]):
+        assert a["loss"] == b["loss"] and a["grad_norm"] == b["grad_norm"] and a["learning_rate"] == b["learning_rate"], (a, b)
+    print("debug_pi05 loss curve", [round(r["loss"], 5) for r in full], "resumed", [round(r["loss"], 5) for r in rest])
