@@ -100,7 +100,8 @@ class GemmTimer:
             s.record()
             r = timer._orig(A, B, out, **kw)
             e.record()
-            timer.events.append((s, e, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1),
+            # act 6 (gate | up pair GEMM): N names the MLP width, the launch multiplies by both weights
+            timer.events.append((s, e, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1) * (2 if kw.get("act", 0) == 6 else 1),
                                  (int(kw.get("a_kc", True)), int(kw.get("b_kc", True)), kw["M"], kw["N"], kw["K"], kw.get("batch", 1))))
             return r
 

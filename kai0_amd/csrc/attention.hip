@@ -20,10 +20,12 @@
 #include "common.h"
 #include "../../include/kai0hip.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
+constexpr int KC_LDS_MAX = 2048;  // key codes staged in LDS per block (8 KiB): covers S = 1018 and the estimator's 1786
 
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, char* lds_dst_wave_uniform) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))lds_dst_wave_uniform, 16, (int)voff, 0, 0, 0);
@@ -37,6 +39,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4v;
 
 struct AttnArgs {
     const bf16_t* Q;
@@ -52,6 +55,9 @@ struct AttnArgs {
     int64_t sQ1, sQ2, sK1, sK2, sV1, sV2, sO1, sO2, sP;
     int64_t qcode_ld, kcode_ld;
     float scale;
+    int kc_lds_keys;  // > 0: the key codes of the launch's key range are staged in LDS once per block (round_up(Sk, 64) entries)
+    int ablate;  // diagnostics only (KAI0_ATTN_ABLATE bit mask, timing runs): 1 no P store, 2 no pass 1, 4 no P V MFMAs,
+                 // 8 no DMA inside the tile loops, 16 no logits MFMAs in pass 2 — results are wrong with any bit set
 };
 
 // NKS = number of 64-wide K sub-tiles (HD <= 64*NKS); VC = V tile columns (128 or 256); OMT = VC/16 output d-tiles
@@ -60,8 +66,9 @@ struct AttnArgs {
 // OP > 0: single pass for Sk <= 64 * OP keys — all OP key tiles (K and V) are staged into LDS at once, the logits of the whole
 // row stay in registers (OP x 4 x QT accumulators), so Q K^T is computed once and there is no per-tile barrier; OP = 0: the
 // general two-pass form (pass 1: row max / sum, pass 2: recompute the logits, P, P V).
-template <int NKS, int VC, int QT, int OP = 0>
+template <int NKS, int VC, int QT, int OP = 0, bool STG = false>
 __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const AttnArgs p) {
+    static_assert(!STG || (QT == 1 && OP == 0), "staggered pass 2: eight waves, two passes");
     constexpr int WAVES = 128 / (16 * QT);
     constexpr int OMT = VC / 16;
     constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     static_assert(NKP >= 1 && NVP >= 1, "too many waves for this tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* pbuf_all = smem + (OP > 0 ? OP : 2) * STAGE;  // WAVES x [16 QT rows][64 keys] bf16 (P transposition scratch)
+    int* kc_lds = reinterpret_cast<int*>(pbuf_all + WAVES * QT * 2048);  // key codes of all keys (see load_kcodes)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,7 +179,24 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     // logits with the reference's rounding, masked: element (mt, nt, r) is key kt*64 + mt*16 + 4g + r, query column l15
     // key codes of tile kt for this lane's 16 keys (mt*16 + 4g + r): loaded BEFORE the tile's MFMAs so that the global
     // latency hides behind them (inside finish_logits they cost one exposed load latency per tile and pass)
+    // The codes depend on the key only: each block copies the whole row into LDS once (the first barrier below publishes it) and a
+    // tile takes its 16 codes with four 16-B LDS reads.  Straight from global they were 16 dword loads per lane per tile and pass,
+    // whose latency the tile's 32 MFMAs do not cover (the forward's phases are latency-bound: KAI0_ATTN_ABLATE shows their costs
+    // simply adding up).
+    if (p.kc_lds_keys > 0) {
+        for (int i = tid; i < p.kc_lds_keys; i += WAVES * 64)
+            kc_lds[i] = p.kcode == nullptr ? 0 : (i < p.Sk ? p.kcode[z1 * p.kcode_ld + i] : INT_MAX);
+    }
     auto load_kcodes = [&](int kt, int (&kc)[4][4]) {
+        if (p.kc_lds_keys > 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const i32x4v c = *reinterpret_cast<const i32x4v*>(kc_lds + kt * 64 + mt * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kc[mt][r] = c[r];
+            }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int key = kt * 64 + mt * 16 + 4 * g;
@@ -203,9 +228,9 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     char* pbuf = pbuf_all + wave * (QT * 2048);
     // one 64-key tile of the output side: final probabilities from the finished logits s (row max m, 1 / row sum inv_l),
     // P written out, O^T += V^T P^T
-    auto emit_tile = [&](int kt, const char* tv, f32x4 (&s)[4][QT], const float (&m_run)[QT], const float (&inv_l)[QT]) {
-        // final probabilities, rounded to bf16 exactly once (what the reference multiplies V with)
-        bf16x4 pb[4][QT];
+    // final probabilities of a 64-key tile from the finished logits s (row max m, 1 / row sum inv_l), rounded to bf16 exactly once
+    // (what the reference multiplies V with), and written out
+    auto make_p = [&](int kt, f32x4 (&s)[4][QT], const float (&m_run)[QT], const float (&inv_l)[QT], bf16x4 (&pb)[4][QT]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -216,7 +241,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
                     pb[mt][nt][r] = f2bf(e);
                 }
         // P tile -> global through a wave-private LDS transposition: write [16 QT q][64 keys] rows, read 16 B per lane
-        if (p.P != nullptr) {
+        if (p.P != nullptr && !(p.ablate & 1)) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -238,10 +263,12 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
-        // O^T += V^T P^T : contraction over the 64 keys in two 32-key steps; step kk uses key blocks 2kk and 2kk+1, lane
-        // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
+    };
+    // O^T += V^T P^T : contraction over the 64 keys in two 32-key steps; step kk uses key blocks 2kk and 2kk+1, lane
+    // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
+    auto pv_tile = [&](const char* tv, const bf16x4 (&pb)[4][QT]) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < ((p.ablate & 4) ? 0 : 2); ++kk) {
             bf16x8 pf[QT];
 #pragma unroll
             for (int nt = 0; nt < QT; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -260,6 +287,11 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
                 for (int nt = 0; nt < QT; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
             }
         }
+    };
+    auto emit_tile = [&](int kt, const char* tv, f32x4 (&s)[4][QT], const float (&m_run)[QT], const float (&inv_l)[QT]) {
+        bf16x4 pb[4][QT];
+        make_p(kt, s, m_run, inv_l, pb);
+        pv_tile(tv, pb);
     };
 
     if constexpr (OP > 0) {
@@ -323,9 +355,9 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     stage(0, 0, false);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    for (int kt = 0; kt < ntiles; ++kt) {
+    for (int kt = 0; kt < ((p.ablate & 2) ? 0 : ntiles); ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, false);
+        if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, false);
         int kc[4][4];
         load_kcodes(kt, kc);
         f32x4 s[4][QT];
@@ -369,23 +401,79 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     }
 
     // ================================ pass 2: P and O = P V ===========================================================
+    if constexpr (STG) {
+        // Staggered form (eight waves = two groups of four, one wave of each per SIMD).  A tile is two barrier slots:
+        //   X(t) = [logits of tile t, mask, exp, P rounded and stored]   (MFMA 1/3 + the softmax VALU work + the P stores)
+        //   Y(t) = [O += P V of tile t]                                   (MFMA 2/3 + the transpose reads of V)
+        // Group 0 runs X(0) | Y(0) | X(1) | ..., group 1 the same sequence one slot later, so on every SIMD one wave is in its
+        // VALU / store heavy X while the other is in its MFMA / LDS heavy Y (measured: with all eight waves in lockstep the costs of
+        // the phases simply add up, KAI0_ATTN_ABLATE).  Slot 2t+1 holds Y(t) of group 0 and X(t) of group 1:
+        //  * both groups issue their DMA pieces of tile t+1 at the START of that slot (group 0 in front of Y(t), group 1 in front of
+        //    X(t)) into buffer (t+1) & 1, whose last readers — Y(t-1) of group 0 in slot 2t-1, of group 1 in slot 2t — retired their
+        //    reads before the barrier that opens slot 2t+1 (WAR);
+        //  * every wave waits for its own pieces at the END of slot 2t+1, in front of the barrier; the first reader of tile t+1 is
+        //    X(t+1) of group 0 in slot 2t+2 (RAW).  Group 1's two P stores of X(t) are younger than its pieces -> vmcnt(2 QT).
+        const int grp = wave >= WAVES / 2 ? 1 : 0;
+        stage(0, 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (grp == 1) lds_barrier();  // one slot behind
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int buf = kt & 1;
+            const char* tk = smem + buf * STAGE;
+            const bool more = kt + 1 < ntiles && !(p.ablate & 8);
+            // ---- X(kt)
+            if (grp == 1 && more) stage(kt + 1, buf ^ 1, true);
+            int kc[4][4];
+            load_kcodes(kt, kc);
+            f32x4 s[4][QT];
+            if (p.ablate & 16) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < QT; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else
+            logits(tk, s);
+            finish_logits(kt, s, kc);
+            bf16x4 pb[4][QT];
+            make_p(kt, s, m_run, inv_l, pb);
+            if (grp == 1) {
+                if (p.P != nullptr && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_barrier();
+            // ---- Y(kt)
+            if (grp == 0 && more) stage(kt + 1, buf ^ 1, true);
+            pv_tile(tk + K_BYTES, pb);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        if (grp == 0) lds_barrier();  // re-align the two groups
+    } else {
     stage(0, 0, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ntiles) stage(kt + 1, buf ^ 1, true);
+        if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, true);
         const char* tk = smem + buf * STAGE;
         int kc[4][4];
         load_kcodes(kt, kc);
         f32x4 s[4][QT];
+        if (p.ablate & 16) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < QT; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else
         logits(tk, s);
         finish_logits(kt, s, kc);
         emit_tile(kt, tk + K_BYTES, s, m_run, inv_l);
         // the DMA of tile kt+1 (issued at the top of this iteration) must have landed; the P stores issued after it may fly
-        if (p.P != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
+        if (p.P != nullptr && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
+    }
     }
     }
     // zero the padding columns [64*ntiles, ldp) of P (none when ldp <= 64*ntiles) — the tiles above already wrote
@@ -434,14 +522,19 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     p.sO1 = d->sO1; p.sO2 = d->sO2; p.sP = d->sP;
     p.qcode_ld = d->qcode_ld; p.kcode_ld = d->kcode_ld;
     p.scale = d->scale;
+    static const int ablate = [] { const char* e = getenv("KAI0_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
+    p.ablate = ablate;
+    static const int kc_lds = [] { const char* e = getenv("KAI0_ATTN_KC_LDS"); return e ? atoi(e) : 1; }();
+    const int kc_keys = ((d->Sk + 63) / 64) * 64;
+    p.kc_lds_keys = (kc_lds && kc_keys <= KC_LDS_MAX) ? kc_keys : 0;  // longer key ranges read their codes from global
     const int batch = d->batch > 0 ? d->batch : 1;
     dim3 grid((d->rows + 127) / 128, batch, 1);
     hipStream_t s = (hipStream_t)stream;
-#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP)                                                                          \
+#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP, STG)                                                                          \
     do {                                                                                                          \
-        constexpr int LDS = (OP > 0 ? OP : 2) * (NKS * 8192 + 64 * VC * 2) + 4 * 4096;                            \
+        constexpr int LDS = (OP > 0 ? OP : 2) * (NKS * 8192 + 64 * VC * 2) + 4 * 4096 + KC_LDS_MAX * 4;          \
         static bool attr_set = false;                                                                             \
-        auto kern = attn_fwd_kernel<NKS, VC, QT, OP>;                                                             \
+        auto kern = attn_fwd_kernel<NKS, VC, QT, OP, STG>;                                                             \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             KAI0_REQUIRE(e == hipSuccess, "kai0_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
@@ -452,15 +545,20 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     // KAI0_ATTN_QT=2: the former four-wave blocks; KAI0_ATTN_ONEPASS=0: always two passes (diagnostics)
     static const int qt = [] { const char* e = getenv("KAI0_ATTN_QT"); return e ? atoi(e) : 1; }();
     static const int onepass = [] { const char* e = getenv("KAI0_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
+    // KAI0_ATTN_STAGGER=1: the two wave groups of pass 2 one barrier slot apart (measured SLOWER: 1.095 vs 0.965 ms — the phases are
+    // latency-bound, two lockstep waves per SIMD already cover each other, and a slot lasts as long as its longer phase)
+    static const int stagger = [] { const char* e = getenv("KAI0_ATTN_STAGGER"); return e ? atoi(e) : 0; }();
     if (d->HD <= 128) {
-        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0);
+        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0, false);
         // 256 keys = 4 resident tiles (144 KiB, one block per CU): wins when the grid is at most a round or two of the chip
         // (B = 1 inference: 26 -> 19 us); with thousands of blocks the two-pass form's two 80-KiB blocks per CU are as fast
-        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4);
-        else KAI0_ATTN_LAUNCH(2, 128, 1, 0);
+        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, false);
+        else if (stagger) KAI0_ATTN_LAUNCH(2, 128, 1, 0, true);
+        else KAI0_ATTN_LAUNCH(2, 128, 1, 0, false);
     } else {
-        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0);
-        else KAI0_ATTN_LAUNCH(4, 256, 1, 0);
+        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, false);
+        else if (stagger) KAI0_ATTN_LAUNCH(4, 256, 1, 0, true);
+        else KAI0_ATTN_LAUNCH(4, 256, 1, 0, false);
     }
 #undef KAI0_ATTN_LAUNCH
     return kai0_check_launch("kai0_attn_fwd");

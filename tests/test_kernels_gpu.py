@@ -403,7 +403,8 @@ def test_gemm_geglu_pair_equals_gate_gemm_plus_up_gemm(ops, M, D, Fd):
     with and without the pre-activation outputs; and against an fp32 reference of the op."""
     x = rnd(M, D, seed=1)
     wg, wu = rnd(Fd, D, seed=2, scale=0.05), rnd(Fd, D, seed=3, scale=0.05)
-    g_ref = ops.linear_fwd(x, wg)
+    g_ref = torch.empty((M, Fd), dtype=BF16, device=dev())
+    ops.gemm(x, wg, g_ref, M=M, N=Fd, K=D, lda=D, ldb=D, ldc=Fd)  # (no split-K: the same summation order as the pair GEMM)
     u_ref, h_ref = torch.empty_like(g_ref), torch.empty_like(g_ref)
     ops.gemm(x, wu, h_ref, M=M, N=Fd, K=D, lda=D, ldb=D, ldc=Fd, act=2, pre_out=u_ref, aux1=g_ref)
     g, u, h = (torch.full_like(g_ref, float("nan")) for _ in range(3))
