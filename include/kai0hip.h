@@ -289,6 +289,10 @@ int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratc
  * out = bf16( bf16(x*cos) + bf16(rot(x)*sin) ).  inverse=1 applies the transpose (backward). */
 int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_freq, int B, int S, int64_t s_ld_rows,
                       int64_t row0, int H, int HD, int inverse, kai0_stream_t stream);
+/* kai0_rope_inplace on two tensors that share the positions — q [B][s_ld_rows][H][HD] and k [B][s_ld_rows][H2][HD] of one
+ * attention layer (modeling_gemma.py:172-194 rotates both with the same cos / sin): one launch, the trigonometry once. */
+int kai0_rope_inplace2(void* x, int H, void* x2, int H2, const int32_t* pos, const float* inv_freq, int B, int S,
+                       int64_t s_ld_rows, int64_t row0, int HD, kai0_stream_t stream);
 /* The same rotation out of place and fully strided (elements): dst[b][s] = rope(src[b][s], pos[b * pos_bs + s]) for B x S
  * rows of H heads.  Used to scatter a segment's q / k into the joint [B][S_total] attention buffers (and to gather the
  * gradients back, inverse = 1) with the rotation applied on the way (gemma_pytorch.py:181-195). */
@@ -400,6 +404,15 @@ int kai0_mse_bwd(const float* u, const float* v, const float* dloss, float* dv, 
                  kai0_stream_t stream);
 /* Euler step x += dt * v (f32) */
 int kai0_euler_step(float* x, const float* v, float dt, int64_t n, kai0_stream_t stream);
+/* The seam between two Euler steps of `sample_actions` in one launch (pi0_pytorch.py:401-461; denoise_step :421-461 +
+ * embed_suffix :237-314): with xs != NULL it CLOSES a step — y = adaRMS(xs, mod) exactly as kai0_adarms_fwd (mod rows
+ * [scale | shift | gate] of leading dimension mod_ld, one per rows_per_batch rows), v_t = action_out_proj(f32(y)) (w_out [A][D],
+ * b_out [A], f32), x_t[rows][A] += dt * v_t in place — and with xs_next != NULL it OPENS the next one — xs_next[rows][D] =
+ * bf16(action_in_proj(x_t)) (w_in [D][A], b_in [D], f32).  Replaces kai0_adarms_fwd + cast + kai0_gemm_f32 + kai0_euler_step +
+ * kai0_gemm_f32 + cast; A <= 64, D % 8 == 0, D <= 2048. */
+int kai0_denoise_glue(const void* xs, const float* mod, int64_t mod_ld, int rows_per_batch, float eps, const float* w_out,
+                      const float* b_out, float* x_t, float dt, const float* w_in, const float* b_in, void* xs_next,
+                      int64_t rows, int D, int A, kai0_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer (train_pytorch.py:469-475,557-561; optimizer.py:15-85).

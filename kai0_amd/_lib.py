@@ -111,6 +111,7 @@ _PROTOS: dict[str, list] = {
     "kai0_reduce_partials": [c_p, c_i, c_i, c_i64, c_p, c_i, c_p],
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
+    "kai0_rope_inplace2": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_p],
     "kai0_rope_copy": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i, c_p],
     "kai0_softmax_mask_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
     "kai0_siglip_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_f, c_p],
@@ -138,6 +139,7 @@ _PROTOS: dict[str, list] = {
     "kai0_mse_fwd": [c_p, c_p, c_p, c_i64, c_p],
     "kai0_mse_bwd": [c_p, c_p, c_p, c_p, c_i64, c_p],
     "kai0_euler_step": [c_p, c_p, c_f, c_i64, c_p],
+    "kai0_denoise_glue": [c_p, c_p, c_i64, c_i, c_f, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
     "kai0_sumsq": [c_p, c_i, c_i64, c_p, c_p, c_p],
     "kai0_clip_coef": [c_p, c_f, c_p, c_p, c_p],
     "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],

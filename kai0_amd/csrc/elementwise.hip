@@ -39,7 +39,9 @@ inline int ew_grid(int64_t n_items, int per_block) {
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src,
                                                    const int32_t* __restrict__ pos, const float* __restrict__ inv_freq, int B,
                                                    int S, int64_t dst_bs, int64_t dst_ld, int64_t src_bs, int64_t src_ld,
-                                                   int64_t pos_bs, int H, int HD, int inverse) {
+                                                   int64_t pos_bs, int H, int HD, int inverse, bf16_t* __restrict__ x2 = nullptr,
+                                                   int64_t x2_bs = 0, int64_t x2_ld = 0, int H2 = 0) {
+    // x2 (optional): a second tensor rotated in place with the SAME positions (k next to q: one launch, the trigonometry once)
     const int tpr = HD >> 3;              // threads per row (HD/2 freqs, 4 per thread)
     const int rpb = 256 / tpr;            // rows per block
     const int rl = threadIdx.x / tpr;
@@ -72,6 +74,22 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ dst, con
             }
             *reinterpret_cast<bf16x4*>(yr + h * HD + i4) = o1;
             *reinterpret_cast<bf16x4*>(yr + h * HD + i4 + (HD >> 1)) = o2;
+        }
+        if (x2 != nullptr) {
+            bf16_t* zr = x2 + (int64_t)b * x2_bs + (int64_t)s * x2_ld;
+            for (int h = 0; h < H2; ++h) {
+                const bf16x4 a = *reinterpret_cast<const bf16x4*>(zr + h * HD + i4);
+                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(zr + h * HD + i4 + (HD >> 1));
+                bf16x4 o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x1 = bf2f(a[e]), x2v = bf2f(bq[e]);
+                    o1[e] = f2bf(rbf(x1 * c[e]) + rbf(-x2v * sn[e]));
+                    o2[e] = f2bf(rbf(x2v * c[e]) + rbf(x1 * sn[e]));
+                }
+                *reinterpret_cast<bf16x4*>(zr + h * HD + i4) = o1;
+                *reinterpret_cast<bf16x4*>(zr + h * HD + i4 + (HD >> 1)) = o2;
+            }
         }
     }
 }
@@ -547,6 +565,19 @@ KAI0_API int kai0_rope_inplace(void* x, const int32_t* pos, const float* inv_fre
                        (const bf16_t*)x + row0 * row, pos, inv_freq, B, S, s_ld_rows * row, row, s_ld_rows * row, row, (int64_t)S, H,
                        HD, inverse);
     return kai0_check_launch("kai0_rope_inplace");
+}
+
+KAI0_API int kai0_rope_inplace2(void* x, int H, void* x2, int H2, const int32_t* pos, const float* inv_freq, int B, int S,
+                                int64_t s_ld_rows, int64_t row0, int HD, kai0_stream_t stream) {
+    KAI0_REQUIRE(x && x2 && pos && inv_freq, "kai0_rope_inplace2: null operand");
+    KAI0_REQUIRE(HD % 8 == 0 && HD >= 8 && HD <= 2048 && 256 % (HD / 8) == 0, "kai0_rope_inplace2: HD=%d unsupported", HD);
+    if (B * S <= 0) return 0;
+    const int rpb = 256 / (HD / 8);
+    const int64_t r1 = (int64_t)H * HD, r2 = (int64_t)H2 * HD;
+    hipLaunchKernelGGL(rope_kernel, dim3(ew_grid((int64_t)B * S, rpb)), dim3(256), 0, S_(stream), (bf16_t*)x + row0 * r1,
+                       (const bf16_t*)x + row0 * r1, pos, inv_freq, B, S, s_ld_rows * r1, r1, s_ld_rows * r1, r1, (int64_t)S, H, HD, 0,
+                       (bf16_t*)x2 + row0 * r2, s_ld_rows * r2, r2, H2);
+    return kai0_check_launch("kai0_rope_inplace2");
 }
 
 KAI0_API int kai0_rope_copy(const void* src, void* dst, const int32_t* pos, const float* inv_freq, int B, int S, int H, int HD,

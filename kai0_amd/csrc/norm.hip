@@ -86,6 +86,99 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
     }
 }
 
+// The seam between two Euler steps of the denoise loop in one launch (pi0_pytorch.py:401-461):
+//   [final adaRMS norm of the expert's last residual stream -> action_out_proj (f32) -> x_t += dt * v_t]   (closes step s)
+//   [action_in_proj (f32) of the new x_t -> bf16 suffix embedding]                                          (opens step s + 1)
+// — six launches on the generic path (adarms, cast, f32 GEMM, euler, f32 GEMM, cast) whose data is a 50 x 32 action block.
+// One block per row.
+// Rounding points as those kernels: y = bf16((x * rstd) * (1 + scale) + shift) with the row statistics summed exactly like
+// rmsnorm_fwd_kernel (same lane partials, same wave reduction); v = f32 dot of bf16-rounded y with W_out + b; x_t = x_t + dt * v;
+// a = f32 dot + b, stored as bf16.  (The f32 dots run k-ascending per lane and are then summed over the wave — another summation
+// order than the MFMA f32 GEMM's, i.e. equal to ~1e-7 relative, not bit for bit.)
+__global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restrict__ xs, const float* __restrict__ mod, int64_t mod_ld,
+                                                           int rpb, float eps, const float* __restrict__ w_out,
+                                                           const float* __restrict__ b_out, float* __restrict__ x_t, float dt,
+                                                           const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                           bf16_t* __restrict__ xs_next, int64_t rows, int D, int A) {
+    // one block per action row; the chain is a handful of dependent memory round trips, so everything independent is in flight at
+    // once: each of the four waves normalises the row itself (16 elements per lane) and takes A / 4 of the outputs of the first dot
+    // with all their weight loads issued up front; the second dot gives every thread D / 256 outputs
+    __shared__ float xa_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int nchunk = D >> 3;
+    if (xs != nullptr) {
+        const bf16_t* xr = xs + row * D;
+        float xv[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                load8(xr + ci * 8, xv[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[c][e] * xv[c][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[c][e] = 0.f;
+            }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)D + eps);
+        const float* mrow = mod + (row / rpb) * mod_ld;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c * 64 + lane;
+            if (ci < nchunk) {
+                float sc[8], sh[8];
+                loadf8(mrow + ci * 8, sc);
+                loadf8(mrow + D + ci * 8, sh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[c][e] = rbf((xv[c][e] * rstd) * (1.0f + sc[e]) + sh[e]);
+            }
+        }
+        // v[j] = <y, W_out[j]> + b_out[j]; wave w takes outputs j = w, w + 4, ... in groups of four
+        for (int j0 = wave; j0 < A; j0 += 16) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+                if (j < A) {
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int ci = c * 64 + lane;
+                        if (ci < nchunk) {
+                            float wv[8];
+                            loadf8(w_out + (int64_t)j * D + ci * 8, wv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[u] += xv[c][e] * wv[e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+                const float t = wave_sum(acc[u]);
+                if (lane == 0 && j < A) xa_s[j] = x_t[row * A + j] + dt * (t + b_out[j]);
+            }
+        }
+        __syncthreads();
+        if (tid < A) x_t[row * A + tid] = xa_s[tid];
+    } else {
+        if (tid < A) xa_s[tid] = x_t[row * A + tid];
+        __syncthreads();
+    }
+    if (xs_next == nullptr) return;
+    // a[n] = <x_t, W_in[n]> + b_in[n]
+    for (int n = tid; n < D; n += 256) {
+        const float* wr = w_in + (int64_t)n * A;
+        float acc = 0.f;
+        for (int j = 0; j < A; ++j) acc += xa_s[j] * wr[j];
+        xs_next[row * D + n] = f2bf(acc + b_in[n]);
+    }
+}
+
 // split-K combine + gated residual + adaRMS (inference denoise loop): one wave per row
 __global__ __launch_bounds__(256) void adarms_combine_kernel(const float* __restrict__ partials, int splits,
                                                              int64_t split_stride, const bf16_t* __restrict__ gate_prev,
@@ -545,6 +638,19 @@ KAI0_API int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gat
                        (const bf16_t*)x, (const float*)nullptr, mod, (bf16_t*)y, (bf16_t*)gate_out, rstd, rows,
                        rows_per_batch, D, eps);
     return kai0_check_launch("kai0_adarms_fwd");
+}
+
+KAI0_API int kai0_denoise_glue(const void* xs, const float* mod, int64_t mod_ld, int rows_per_batch, float eps, const float* w_out,
+                               const float* b_out, float* x_t, float dt, const float* w_in, const float* b_in, void* xs_next,
+                               int64_t rows, int D, int A, kai0_stream_t stream) {
+    CHECK_D("kai0_denoise_glue", D);
+    KAI0_REQUIRE(x_t && A >= 1 && A <= 64 && (xs == nullptr || (mod && w_out && b_out && rows_per_batch > 0 && mod_ld >= 2 * (int64_t)D)) &&
+                     (xs_next == nullptr || (w_in && b_in)) && (xs != nullptr || xs_next != nullptr),
+                 "kai0_denoise_glue: bad arguments (A <= 64; closing a step needs xs, mod, w_out, b_out; opening one w_in, b_in, xs_next)");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(denoise_glue_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xs, mod,
+                       mod_ld, rows_per_batch, eps, w_out, b_out, x_t, dt, w_in, b_in, (bf16_t*)xs_next, rows, D, A);
+    return kai0_check_launch("kai0_denoise_glue");
 }
 
 KAI0_API int kai0_adarms_combine(const float* partials, int splits, int64_t split_stride, const void* gate_prev,

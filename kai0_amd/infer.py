@@ -86,6 +86,7 @@ class InferenceEngine:
             self._build_skinny()
         self._build_stacked()
         self._times_dev = {}
+        self.glue = os.environ.get("KAI0_INFER_GLUE", "1") != "0"
         self._mods_cache = {}
         self.cache_mods = os.environ.get("KAI0_INFER_CACHE_MODS", "1") != "0"
         self._graph = None
@@ -304,8 +305,7 @@ class InferenceEngine:
             gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
                  c_map=(P, S_ld, 0), segs=[(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)],
                  split_k=_PREFIX_SPLITS[0] or 1)  # fmt: skip
-            ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
-            ops.rope_(self.q_buf, self.pos_prefix, inv_freq, B, P, S_ld, 0, H, HD)
+            ops.rope2_(self.q_buf, H, self.k_cache[l], 1, self.pos_prefix, inv_freq, B, P, S_ld, 0, HD)  # q and k: one launch
             self._attend(l, 0, P, P, qcode, kcode)
             xp = self._oproj(at.o_proj, P, 0, residual=xp)
             hp = ops.rmsnorm(xp, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
@@ -349,7 +349,7 @@ class InferenceEngine:
         c0 = idx * 3 * De + 2 * De
         return self._gates[rows, c0 : c0 + De]
 
-    def _expert_stack_inblock(self, xs, mods, mf, rows):
+    def _expert_stack_inblock(self, xs, mods, mf, rows, final_norm: bool = True):
         """All expert layers of one denoise step, 6 launches per layer and no partial products: [adaRMS -> q|k|v + RoPE],
         logits, softmax + P V, [o_proj + gated residual], [adaRMS -> gate|up + GeGLU], [down_proj + gated residual].  The norms
         run as prologues of the projections that consume them; the gates are precomputed for all steps (`_gate`)."""
@@ -379,6 +379,8 @@ class InferenceEngine:
             xs = torch.empty((M, De), dtype=BF16, device=dev)
             ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
                             gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=self.packed)  # fmt: skip
+        if not final_norm:
+            return xs  # the step seam (kai0_denoise_glue) applies the final norm
         out, _ = ops.adarms(xs, mf[rows].contiguous(), Hs, self.pe.gemma_expert.model.norm.eps)
         return out
 
@@ -473,6 +475,24 @@ class InferenceEngine:
                 ops.transpose_strided(self.v_all, self.vt_all, R=self.P, C=self.HD, src_ld=self.HD, dst_ld=self.S_ld,
                                       batch=self.L * self.B, src_bs=self.S_ld * self.HD, dst_bs=self.HD * self.S_ld)
         x_t = noise.clone().contiguous()
+        if self.skinny and self.inblock and self.decode_attn and self.glue:
+            # step seams in one launch each (kai0_denoise_glue): [final adaRMS -> action_out_proj -> Euler update] of step s and
+            # [action_in_proj -> bf16] of step s + 1 — six launches on the path below
+            model, B, Hs, De = self.model, self.B, self.Hs, self.De
+            M, n = B * Hs, len(times)
+            x2 = x_t.view(M, self.A)
+            win, bin_ = model.action_in_proj.weight, model.action_in_proj.bias
+            wout, bout = model.action_out_proj.weight, model.action_out_proj.bias
+            eps = self.pe.gemma_expert.model.norm.eps
+            xs = torch.empty((M, De), dtype=BF16, device=self.dev)
+            ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs)
+            for step in range(n):
+                rows = slice(step * B, (step + 1) * B)
+                last = self._expert_stack_inblock(xs, mods, mf, rows, final_norm=False)
+                xs = torch.empty((M, De), dtype=BF16, device=self.dev) if step + 1 < n else None
+                ops.denoise_glue(x2, xs=last, mod=mf[rows], mod_ld=self._mod_ld, rows_per_batch=Hs, eps=eps, w_out=wout, b_out=bout,
+                                 dt=dt, w_in=win if xs is not None else None, b_in=bin_ if xs is not None else None, xs_next=xs)
+            return x_t
         for step in range(len(times)):
             v_t = self._denoise_step(x_t, step, mods, mf)
             ops.euler_step_(x_t, v_t, dt)

@@ -1178,6 +1178,12 @@ def rope_(x, pos, inv_freq, Bn, S, s_ld, row0, H, HD, inverse=False):
               int(inverse), _stream())  # fmt: skip
 
 
+def rope2_(x, H, x2, H2, pos, inv_freq, Bn, S, s_ld, row0, HD):
+    """kai0_rope_inplace2: rotate q (H heads) and k (H2 heads) of one layer in place with one launch."""
+    _lib.call("kai0_rope_inplace2", x.data_ptr(), H, x2.data_ptr(), H2, pos.data_ptr(), inv_freq.data_ptr(), Bn, S, s_ld, row0, HD,
+              _stream())
+
+
 def rope_copy(src_t, dst_t, pos, inv_freq, Bn, S, H, HD, *, src, dst, pos_bs, pos_off=0, inverse=False):
     """dst[b][dst_row0 + s] = rope(src[b][src_row0 + s], pos[b][pos_off + s]) (kai0_rope_copy).  `src` / `dst` =
     (batch stride, row stride, first row) in elements / rows of the tensors' data pointers (which may be column slices)."""
@@ -1466,6 +1472,19 @@ class MseFn(torch.autograd.Function):
 
 def mse_loss(u, v):
     return MseFn.apply(u, v)
+
+
+def denoise_glue(x_t, *, xs=None, mod=None, mod_ld=0, rows_per_batch=1, eps=1e-6, w_out=None, b_out=None, dt=0.0, w_in=None,
+                 b_in=None, xs_next=None):
+    """kai0_denoise_glue: close a denoise step (final adaRMS -> action_out_proj -> Euler update of x_t, in place) and / or open
+    the next one (action_in_proj -> bf16 suffix embedding) in one launch.  x_t: f32 [rows, A] contiguous."""
+    rows, A = x_t.shape[0], x_t.shape[1]
+    D = (xs if xs is not None else xs_next).shape[1]
+    for t in (x_t, w_out, b_out, w_in, b_in, mod):
+        if t is not None and t.dtype != F32:
+            raise TypeError("denoise_glue: x_t, weights, biases and modulations are f32")
+    _lib.call("kai0_denoise_glue", _p(xs), _p(mod), mod_ld, rows_per_batch, eps, _p(w_out), _p(b_out), x_t.data_ptr(), dt, _p(w_in),
+              _p(b_in), _p(xs_next), rows, D, A, _stream())
 
 
 def euler_step_(x, v, dt: float):

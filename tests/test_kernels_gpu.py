@@ -1038,3 +1038,49 @@ def test_skinny_inblock_packed_weights_are_bit_identical(ops):
         got.append((q, k, vt, h))
     for a_, b_, name in zip(got[0], got[1], ("q", "k", "vt", "h")):
         assert torch.equal(a_, b_), name
+
+
+@pytest.mark.parametrize("B,Hs", [(1, 50), (2, 7)])
+def test_denoise_glue_equals_the_six_launches_it_replaces(ops, B, Hs):
+    """kai0_denoise_glue (step seam of the denoise loop) against adarms -> cast -> f32 GEMM -> Euler -> f32 GEMM -> cast: the Euler
+    state to f32 round-off (another summation order in the two dots), the next suffix embedding to one bf16 ulp; and the two
+    one-sided forms (open only / close only)."""
+    De, A, M = 1024, 32, B * Hs
+    xs = rnd(M, De, seed=1)
+    mod_all = rnd(B, 5 * De, dtype=F32, seed=2, scale=0.3)  # a wider row: the modulation is a strided view (leading dimension 5 De)
+    mod = mod_all[:, De : 4 * De]
+    w_out, b_out = rnd(A, De, dtype=F32, seed=3, scale=0.05), rnd(A, dtype=F32, seed=4, scale=0.1)
+    w_in, b_in = rnd(De, A, dtype=F32, seed=5, scale=0.2), rnd(De, dtype=F32, seed=6, scale=0.1)
+    x0 = rnd(M, A, dtype=F32, seed=7)
+    dt = -0.1
+    y, _ = ops.adarms(xs, mod.contiguous(), Hs, 1e-6)
+    v = ops.linear_f32(ops.cast(y, F32), w_out, b_out)
+    x_ref = x0.clone()
+    ops.euler_step_(x_ref, v, dt)
+    xs_ref = ops.cast(ops.linear_f32(x_ref, w_in, b_in), BF16)
+    x_t, xs_next = x0.clone(), torch.full((M, De), float("nan"), dtype=BF16, device=dev())
+    ops.denoise_glue(x_t, xs=xs, mod=mod, mod_ld=5 * De, rows_per_batch=Hs, eps=1e-6, w_out=w_out, b_out=b_out, dt=dt, w_in=w_in,
+                     b_in=b_in, xs_next=xs_next)
+    assert torch.allclose(x_t, x_ref, rtol=1e-5, atol=1e-5), float((x_t - x_ref).abs().max())
+    assert rel_err(xs_next, xs_ref) < 2e-3 and float((xs_next.float() - xs_ref.float()).abs().max()) <= 2 ** -7 * float(xs_ref.float().abs().max())
+    # close only: x_t updated, nothing else written; open only: x_t untouched
+    x_c = x0.clone()
+    ops.denoise_glue(x_c, xs=xs, mod=mod, mod_ld=5 * De, rows_per_batch=Hs, eps=1e-6, w_out=w_out, b_out=b_out, dt=dt)
+    assert torch.equal(x_c, x_t)
+    x_o, xs_o = x_ref.clone(), torch.empty((M, De), dtype=BF16, device=dev())
+    ops.denoise_glue(x_o, w_in=w_in, b_in=b_in, xs_next=xs_o)
+    assert torch.equal(x_o, x_ref) and rel_err(xs_o, xs_ref) < 2e-3
+
+
+def test_rope_two_tensors_in_one_launch(ops):
+    """kai0_rope_inplace2 (q and k of a layer, shared positions) == two kai0_rope_inplace calls, bit for bit."""
+    B, S, S_ld, H, HD = 2, 37, 40, 8, 256
+    q, k = rnd(B, S_ld, H * HD, seed=1), rnd(B, S_ld, HD, seed=2)
+    pos = torch.randint(0, 900, (B, S), dtype=torch.int32, device=dev())
+    inv = (1.0 / (10000.0 ** (torch.arange(0, HD, 2, dtype=torch.float32) / HD))).to(dev())
+    q1, k1 = q.clone(), k.clone()
+    ops.rope_(q1, pos, inv, B, S, S_ld, 0, H, HD)
+    ops.rope_(k1, pos, inv, B, S, S_ld, 0, 1, HD)
+    q2, k2 = q.clone(), k.clone()
+    ops.rope2_(q2, H, k2, 1, pos, inv, B, S, S_ld, 0, HD)
+    assert torch.equal(q1, q2) and torch.equal(k1, k2) and not torch.equal(q1, q)
