@@ -20,7 +20,10 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return OUT
     OUT.parent.mkdir(parents=True, exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off",
+    import os
+
+    extra = os.environ.get("KAI0_HIPCC_FLAGS", "").split()  # e.g. -DKAI0_SK2_TRACE (tools/probes/sk2_phases.py)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", *extra,
            *map(str, srcs), "-o", str(OUT)]  # fmt: skip
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -103,13 +103,40 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
     // one block per action row; the chain is a handful of dependent memory round trips, so everything independent is in flight at
     // once: each of the four waves normalises the row itself (16 elements per lane) and takes A / 4 of the outputs of the first dot
     // with all their weight loads issued up front; the second dot gives every thread D / 256 outputs
-    __shared__ float xa_s[64];
+    __shared__ float xa_s[64], x0_s[64], bo_s[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const int nchunk = D >> 3;
+    if (tid < A) {  // requested at kernel entry, read after the dots
+        x0_s[tid] = x_t[row * A + tid];
+        bo_s[tid] = xs != nullptr ? b_out[tid] : 0.f;
+    }
+    __syncthreads();
     if (xs != nullptr) {
         const bf16_t* xr = xs + row * D;
         float xv[MAXC][8];
+        const float* mrow = mod + (row / rpb) * mod_ld;
+        if (A == 32 && D == 1024) {
+            // the row, its scale and its shift: six unconditional 16 / 32-byte loads per lane, all in flight before the statistics
+            float sc[2][8], sh[2][8];
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                load8(xr + (c * 64 + lane) * 8, xv[c]);
+                loadf8(mrow + (c * 64 + lane) * 8, sc[c]);
+                loadf8(mrow + 1024 + (c * 64 + lane) * 8, sh[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[c][e] * xv[c][e];
+            ss = wave_sum(ss);
+            const float rstd = rsqrtf(ss / 1024.0f + eps);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[c][e] = rbf((xv[c][e] * rstd) * (1.0f + sc[c][e]) + sh[c][e]);
+        } else {
         float ss = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -125,7 +152,6 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
         }
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss / (float)D + eps);
-        const float* mrow = mod + (row / rpb) * mod_ld;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ci = c * 64 + lane;
@@ -137,7 +163,37 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
                 for (int e = 0; e < 8; ++e) xv[c][e] = rbf((xv[c][e] * rstd) * (1.0f + sc[e]) + sh[e]);
             }
         }
+        }
         // v[j] = <y, W_out[j]> + b_out[j]; wave w takes outputs j = w, w + 4, ... in groups of four
+        if (A == 32 && D == 1024) {
+            // pi0.5's shape, no run-time conditions around the loads (hipcc branches around a conditional load and waits for each one:
+            // sixteen dependent round trips): wave w owns outputs w, w + 4, ..., w + 28; 32 16-B loads per lane in flight
+            float acc[8];
+            f32x4 wv[8][2][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float* wp = w_out + (int64_t)(wave + 4 * u) * 1024 + (c * 64 + lane) * 8;
+                    wv[u][c][0] = *reinterpret_cast<const f32x4*>(wp);
+                    wv[u][c][1] = *reinterpret_cast<const f32x4*>(wp + 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a += xv[c][e] * wv[u][c][e >> 2][e & 3];
+                acc[u] = a;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float t = wave_sum(acc[u]);
+                const int j = wave + 4 * u;
+                if (lane == 0) xa_s[j] = x0_s[j] + dt * (t + bo_s[j]);
+            }
+        } else
         for (int j0 = wave; j0 < A; j0 += 16) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -160,17 +216,42 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
             for (int u = 0; u < 4; ++u) {
                 const int j = j0 + 4 * u;
                 const float t = wave_sum(acc[u]);
-                if (lane == 0 && j < A) xa_s[j] = x_t[row * A + j] + dt * (t + b_out[j]);
+                if (lane == 0 && j < A) xa_s[j] = x0_s[j] + dt * (t + bo_s[j]);
             }
         }
         __syncthreads();
         if (tid < A) x_t[row * A + tid] = xa_s[tid];
     } else {
-        if (tid < A) xa_s[tid] = x_t[row * A + tid];
+        if (tid < A) xa_s[tid] = x0_s[tid];
         __syncthreads();
     }
     if (xs_next == nullptr) return;
-    // a[n] = <x_t, W_in[n]> + b_in[n]
+    // a[n] = <x_t, W_in[n]> + b_in[n]; A == 32 (pi0.5): the 128-B weight row as eight 16-B loads, four outputs per thread, all
+    // loads of a thread in flight before the first multiply
+    if (A == 32 && D == 1024) {
+        f32x4 w[4][8];
+        float bi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = tid + 256 * u;
+            bi[u] = b_in[n];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[u][q] = *reinterpret_cast<const f32x4*>(w_in + (int64_t)n * 32 + 4 * q);
+        }
+        float xa[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xa[j] = xa_s[j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += xa[4 * q + e] * w[u][q][e];
+            xs_next[row * D + tid + 256 * u] = f2bf(acc + bi[u]);
+        }
+        return;
+    }
     for (int n = tid; n < D; n += 256) {
         const float* wr = w_in + (int64_t)n * A;
         float acc = 0.f;

@@ -276,6 +276,18 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny_kernel(const SkinnyArgs p) 
 //   hundred KB of activations out of L2, and the direct fragment pattern (16 rows x 64 B per wave-instruction) gets 31-34 GB/s
 //   per CU there against 80-90 GB/s for contiguous runs (tools/probes/frag_load.hip: 128 KB per CU 4.8 vs 2.8 us, 256 KB 8.2 vs
 //   3.3 us): in the 1024-column projections the A operand, not the weight stream, was the longer load.
+// diagnostics (a workspace passed with split_k == -1 = phase trace, int64 [blocks][8]): wave 0 stamps the shader clock at the
+// phase boundaries of its block
+// (compiled in only with -DKAI0_SK2_TRACE: the eight extra branches split the kernel's basic blocks and cost the denoise loop 5 %)
+#ifdef KAI0_SK2_TRACE
+#define SK2_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (trace != nullptr && tid == 0) trace[(int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define SK2_STAMP(i) do { (void)trace; } while (0)
+#endif
+
 template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false>
 __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p) {
     constexpr int TMB = 16 * MTL;
@@ -296,6 +308,14 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x, mt_blk = blockIdx.z;
+    // Every kernel argument the block will need is pulled into SGPRs HERE, in one batch of scalar loads.  Left to itself hipcc loads
+    // each field of the by-value struct next to its first use, behind the branch that guards it: eight serial s_load / s_waitcnt
+    // round trips (~2700 clocks, 1.3 us) stood in front of the first weight load of every launch (tools/probes/sk2_phases.py).
+    asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.lda), "s"(p.ldw), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.pair_stride), "s"(p.mode),
+                 "s"(p.amap.rpb), "s"(p.amap.bs), "s"(p.amap.off), "s"(p.mod), "s"(p.mod_rpb), "s"(p.mod_ld), "s"(p.w_packed),
+                 "s"(p.ws));
+    long long* trace = reinterpret_cast<long long*>(p.ws);
+    SK2_STAMP(0);
     int n_sub0, n_sub1;
     if constexpr (PAIR) {
         const int per = p.pair_stride >> 4;
@@ -352,28 +372,58 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
         const float* mrow = p.mod + (int64_t)(m0 / p.mod_rpb) * p.mod_ld;
 #pragma unroll
         for (int q = 0; q < (2 * KB / 4 + NW * 64 - 1) / (NW * 64); ++q) {
-            const int idx = q * (NW * 64) + tid;  // 16-B piece of [scale (K) | shift (K)]
-            mod_piece[q] = idx < 2 * KB / 4 ? *reinterpret_cast<const f32x4*>(mrow + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // 16-B piece of [scale (K) | shift (K)]; the index is clamped instead of guarded: a conditional load is compiled as a
+            // branch with its own vmcnt(0), which held back every load issued after it by one memory round trip
+            const int idx = min(q * (NW * 64) + tid, 2 * KB / 4 - 1);
+            mod_piece[q] = *reinterpret_cast<const f32x4*>(mrow + idx * 4);
         }
     }
     if constexpr (ALDS) {
-        // the block's TMB x K tile of A: 16-B chunks, consecutive lanes on consecutive chunks of a row
+        // the block's TMB x K tile of A: 16-B chunks, consecutive lanes on consecutive chunks of a row.  Loaded through a buffer
+        // descriptor with 32-bit offsets: a row past the tile's end gets an out-of-range offset (the hardware returns zeros), so
+        // all NCH loads are unconditional and issued back to back.  (With `row < m_end ? load : 0` and the 64-bit row map hipcc
+        // emitted an exec-masked branch, a signed division and a 64-bit multiply PER CHUNK — ~1300 instructions, ~3 us, in front of
+        // the gate | up launch's last load.)  The row map is evaluated once per thread and stepped: a thread's chunks are RPQ rows apart.
         constexpr int CPR = KB / 8;                         // chunks per row
         constexpr int NCH = TMB * CPR / (NW * 64);          // chunks per thread
-        static_assert((TMB * CPR) % (NW * 64) == 0, "A tile must divide over the block's threads");
+        constexpr int RPQ = NW * 64 / CPR;                  // rows between a thread's consecutive chunks
+        static_assert((TMB * CPR) % (NW * 64) == 0 && (NW * 64) % CPR == 0, "A tile must divide over the block's threads");
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)0x80000000u, 0x00020000);
+        const int r0 = tid / CPR, c8 = tid - r0 * CPR;
+        int quot = 0, rem = m0 + r0;                        // row m0 + r0 = quot * rpb + rem
+        if (p.amap.rpb != 0) {
+            quot = rem / p.amap.rpb;
+            rem -= quot * p.amap.rpb;
+        }
+        const uint32_t lda2 = (uint32_t)p.lda * 2, bs2 = (uint32_t)p.amap.bs * lda2;
+        const uint32_t base = (uint32_t)p.amap.off * lda2 + (uint32_t)c8 * 16;
         bf16x8 ch[NCH];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const int cidx = q * (NW * 64) + tid;
-            const int r = cidx / CPR, c8 = cidx - r * CPR;
-            const int row = m0 + r;
-            ch[q] = row < m_end ? *reinterpret_cast<const bf16x8*>(p.A + p.amap(row) * p.lda + c8 * 8) : zero8;
+            const int row = m0 + r0 + q * RPQ;
+            uint32_t off = (uint32_t)quot * bs2 + (uint32_t)rem * lda2 + base;
+            if (row >= m_end) off = 0x80000000u;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
+            ch[q] = __builtin_bit_cast(bf16x8, v);
+            rem += RPQ;
+            if (p.amap.rpb != 0) {
+                if (p.amap.rpb >= RPQ) {  // one step at most (select, no branch)
+                    const bool wrap = rem >= p.amap.rpb;
+                    rem -= wrap ? p.amap.rpb : 0;
+                    quot += wrap ? 1 : 0;
+                } else {  // batch entries shorter than a thread's row step (tests): plain division
+                    const int nr = m0 + r0 + (q + 1) * RPQ;
+                    quot = nr / p.amap.rpb;
+                    rem = nr - quot * p.amap.rpb;
+                }
+            }
         }
+        SK2_STAMP(1);  // every load of the block issued
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int cidx = q * (NW * 64) + tid;
-            const int r = cidx / CPR, c8 = cidx - r * CPR;
-            *reinterpret_cast<bf16x8*>(sk2_smem + r * A_ROWB + c8 * 16) = ch[q];
+            const int r = cidx / CPR;
+            *reinterpret_cast<bf16x8*>(sk2_smem + r * A_ROWB + (cidx - r * CPR) * 16) = ch[q];
         }
         if constexpr (ADA) {
 #pragma unroll
@@ -383,6 +433,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
             }
         }
         __syncthreads();
+        SK2_STAMP(2);  // A tile in LDS
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -419,6 +470,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
             if (g == 0) ssq[wave][mt * 16 + i] = ss;
         }
         __syncthreads();
+        SK2_STAMP(3);  // row statistics exchanged
         float rstd[MTL];
 #pragma unroll
         for (int mt = 0; mt < MTL; ++mt) {
@@ -446,6 +498,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
             }
     }
 
+    SK2_STAMP(4);  // A fragments ready (normalised)
     f32x4 acc[MTL][PAIR ? 2 : 1];
 #pragma unroll
     for (int mt = 0; mt < MTL; ++mt)
@@ -461,6 +514,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
                 for (int s2 = 0; s2 < (PAIR ? 2 : 1); ++s2)
                     acc[mt][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c][mt][j], wf[c][s2][j], acc[mt][s2], 0, 0, 0);
     if constexpr (ALDS) __syncthreads();  // `red` aliases the A tile: every wave has its fragments in registers by now
+    SK2_STAMP(5);  // weights landed, MFMAs issued
 #pragma unroll
     for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
@@ -468,6 +522,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][mt * 16 + 4 * g + r][s2 * 16 + i] = acc[mt][s2][r];
     __syncthreads();
+    SK2_STAMP(6);  // wave partials in LDS
     if (tid >= TMB * 4) return;  // TMB rows x 4 column quads finish the tile
     const int row = tid >> 2, q = tid & 3;
     float v0[4], v1[4];
@@ -483,8 +538,8 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
         v1[e] = s1;
     }
     const int mrow = m0 + row;
-    if (mrow >= m_end) return;
-    sk_epilogue(p, v0, v1, mrow, n_sub0 + 4 * q, n_sub1 + 4 * q, PAIR);
+    if (mrow < m_end) sk_epilogue(p, v0, v1, mrow, n_sub0 + 4 * q, n_sub1 + 4 * q, PAIR);
+    SK2_STAMP(7);  // epilogue stores issued
 }
 
 __global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restrict__ pos, const float* __restrict__ inv_freq,
@@ -645,8 +700,18 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
     a.rope_sin = d->rope_sin;
     a.rope_half = d->rope_half > 0 ? d->rope_half : ps;
     KAI0_REQUIRE(!d->w_packed || (inblock && d->K % 32 == 0 && d->N % 16 == 0), "kai0_gemm_skinny_bf16: w_packed needs split_k == -1");
+    if (inblock) {  // the in-block kernels address A with 32-bit byte offsets below a 2 GiB buffer descriptor
+        const int64_t a_rows = d->a_rpb ? ((int64_t)(d->M / d->a_rpb) + 1) * d->a_bs + d->a_off + d->a_rpb : (int64_t)d->M;
+        KAI0_REQUIRE(a_rows * d->lda * 2 < (int64_t)0x7FFF0000, "kai0_gemm_skinny_bf16: A spans more than 2 GiB (%lld rows)", (long long)a_rows);
+    }
     a.w_packed = d->w_packed;
-    if (inblock) return skinny_inblock(d, a, (hipStream_t)stream);
+    if (inblock) {
+        if (d->workspace != nullptr) {  // diagnostics: phase trace, int64 [row tiles x column tiles][8]
+            KAI0_REQUIRE(((uintptr_t)d->workspace % 8) == 0 && d->workspace_bytes >= 8 * 8 * 4096, "kai0_gemm_skinny_bf16: trace buffer too small");
+            a.ws = (float*)d->workspace;
+        }
+        return skinny_inblock(d, a, (hipStream_t)stream);
+    }
     KAI0_REQUIRE(d->mod == nullptr, "kai0_gemm_skinny_bf16: the adaRMS prologue needs split_k == -1");
     const int tiles = d->N / TN, mtiles = (d->M + TM - 1) / TM;
     if (S > 1) {

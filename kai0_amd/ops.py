@@ -170,6 +170,8 @@ def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int =
         if workspace is None or workspace.dtype != F32:
             raise _lib.Kai0HipError("skinny_gemm: split_k > 1 writes f32 partial products into `workspace` (skinny_workspace)")
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * 4
+    elif split_k == -1 and workspace is not None:  # diagnostics: phase trace of the in-block kernels (tools/probes/sk2_phases.py)
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if mod is not None:
         if mod.dtype != F32 or not mod.is_cuda or mod.stride(-1) != 1:
             raise _lib.Kai0HipError("skinny_gemm: mod must be an f32 CUDA (HIP) tensor with unit inner stride")

@@ -20,5 +20,12 @@ for C in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
   python tools/pmc_summary.py /tmp/pmc_$DN 14 > $OUT/pmc_$DN.txt 2>&1
 done
 python tools/gemm_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/gemm_traffic.json > $OUT/gemm_traffic.log 2>&1
+# the action chunk's HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE, eager launches) against the durations of the un-counted trace above
+for C in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
+  CN="${C%%:*}"; DN="${C##*:}"
+  timeout 600 rocprofv3 --pmc $CN --kernel-trace -d /tmp/pmc_inf_$DN -o p --output-format csv -- python tools/infer_once.py 2 0 > $OUT/pmc_inf_$DN.log 2>&1
+done
+python tools/infer_pmc.py /tmp/pmc_inf_fetch /tmp/pmc_inf_write $(find /tmp/prof_inf -name "*.db" | head -1) 30 > $OUT/infer_chunk_pmc.txt 2>&1
+python tools/overlap_summary.py $(find /tmp/prof_train -name "*.db" | head -1) 2 > $OUT/train_overlap.txt 2>&1
 grep -h '"metric"' $OUT/*.log | cut -c1-600
 ls -la $OUT
