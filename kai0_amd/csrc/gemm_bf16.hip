@@ -95,7 +95,8 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t vof
 // The fused epilogue on 8 consecutive columns [ccol, ccol+8) of output row `row` (v = f32 accumulators), shared by the
 // GEMM kernel and the split-K reduction.  Order and rounding points: see kai0hip.h.
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int row, int ccol, int64_t cz, int64_t rz,
-                                          int64_t vz, void* cbase, bool raw_f32) {
+                                          int64_t vz, void* cbase, bool raw_f32, const bf16x8* res_pre = nullptr) {
+    // res_pre: the residual operand already loaded by the caller (requested together with its other loads)
     // raw_f32: f32 output keeps the raw accumulator (no bf16 rounding points): gradients that must not be quantised
     // before a cancelling reduction (softmax backward) and split-K partial tiles.
     const bool rnd = !raw_f32;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         for (int e = 0; e < 8; ++e) v[e] = R(v[e] * bf2f(gv[e]));
     }
     if (p.residual != nullptr) {
-        bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
+        bf16x8 rv = res_pre != nullptr ? *res_pre : *reinterpret_cast<const bf16x8*>(p.residual + rz + orow * p.ldr + ccol);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = R(v[e] + bf2f(rv[e]));
     }
@@ -223,6 +224,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         *reinterpret_cast<bf16x8*>(cp) = ov;
     }
 }
+
+#define N_ALIGNED8(n) (((n) & 7) == 0)
 
 // block barrier that does NOT drain the LDS-DMA queue behind the compiler's back: the kernel places its own vmcnt.
 __device__ __forceinline__ void lds_barrier() {
@@ -776,6 +779,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const bool fused_fast = p.act >= 2 && p.split_k == 1 && p.bias == nullptr && p.gate == nullptr && p.residual == nullptr &&
                             !p.accumulate && !p.out_f32 && p.nseg == 0 && (p.act == 4 || p.scale == 1.0f) &&
                             (p.act != 3 || p.pre_out != nullptr);
+    // plain epilogues that read operands (bias and / or residual; optional GELU): see epi_half
+    const bool plain_fast = p.act <= 1 && p.split_k == 1 && (p.bias != nullptr || p.residual != nullptr) && p.gate == nullptr &&
+                            !p.accumulate && !p.out_f32 && p.nseg == 0 && (N_ALIGNED8(p.N));
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         if (pair) {
@@ -907,6 +913,82 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             __builtin_amdgcn_wave_barrier();
             return;
         }
+        if constexpr (MT == 4) if (plain_fast) {  // (128x128 configurations: in the 256x256 kernels the operand registers went to scratch)
+            // bias / GELU / residual epilogue with its operands requested up front: the bias once (a lane's 8 columns are the same for
+            // all of its rows), the 8 residual rows of the half before the accumulators go to the slab.  In the rolled loop below every
+            // iteration waited out a bias and a residual round trip of its own — most of the fixed cost of the small (B = 1) GEMMs.
+            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && col_ok) {
+                if (p.bias_f32) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.bias) + ccol);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.bias) + ccol + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                } else {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bias) + ccol);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = bf2f(b[e]);
+                }
+            }
+            bf16x8 rs[8];
+            const int rbase = row_base(h) + (lane >> 3);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + it * 8;
+                rs[it] = bf16x8{};
+                if (p.residual != nullptr && row < p.M && col_ok) rs[it] = *reinterpret_cast<const bf16x8*>(p.residual + rz + p.cmap(row) * p.ldr + ccol);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            bf16_t* cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + it * 8;
+                const float* sp = slab + (it * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                if (row >= p.M || !col_ok) continue;
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int64_t o = cz + p.cmap(row) * p.ldc + ccol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);  // same order and rounding points as epilogue8
+                if (p.scale != 1.0f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * p.scale);
+                }
+                if (p.act == 1) {
+                    if (p.pre_out != nullptr) {
+                        bf16x8 pv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
+                        *reinterpret_cast<bf16x8*>(p.pre_out + o) = pv;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 a = gelu_tanh2(f32x2{v[e], v[e + 1]});
+                        v[e] = rbf(a[0]);
+                        v[e + 1] = rbf(a[1]);
+                    }
+                }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rs[it][e]));
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+                *reinterpret_cast<bf16x8*>(cb + o) = ov;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -953,6 +1035,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         const int row = (int)(i / n8);
         const int col = (int)(i - (int64_t)row * n8) * 8;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bf16x8 rpre = {};
+        const bool has_res = p.residual != nullptr && p.act != 4;
+        if (has_res) rpre = *reinterpret_cast<const bf16x8*>(p.residual + rz + p.cmap(row) * p.ldr + col);  // with the partials
+        if (p.split_k <= 8) {
+            // all partial tiles requested before the first add (clamped slice index instead of a loop bound: nothing conditional
+            // around the loads); summed in slice order as below
+            f32x4 a[8], b[8];
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+                const float* wp = w0 + ((int64_t)min(sp, p.split_k - 1) * p.M + row) * p.N + col;
+                a[sp] = *reinterpret_cast<const f32x4*>(wp);
+                b[sp] = *reinterpret_cast<const f32x4*>(wp + 4);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+                const float m = sp < p.split_k ? 1.0f : 0.0f;  // (x * 1 is exact; slices past the end contribute + 0)
+                acc[0] += m * a[sp][0]; acc[1] += m * a[sp][1]; acc[2] += m * a[sp][2]; acc[3] += m * a[sp][3];
+                acc[4] += m * b[sp][0]; acc[5] += m * b[sp][1]; acc[6] += m * b[sp][2]; acc[7] += m * b[sp][3];
+            }
+        } else
         for (int sp = 0; sp < p.split_k; ++sp) {
             const float* wp = w0 + ((int64_t)sp * p.M + row) * p.N + col;
             f32x4 a = *reinterpret_cast<const f32x4*>(wp);
@@ -960,7 +1062,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             acc[0] += a[0]; acc[1] += a[1]; acc[2] += a[2]; acc[3] += a[3];
             acc[4] += b[0]; acc[5] += b[1]; acc[6] += b[2]; acc[7] += b[3];
         }
-        epilogue8(p, acc, row, col, cz, rz, vz, p.C, p.out_f32 != 0);
+        epilogue8(p, acc, row, col, cz, rz, vz, p.C, p.out_f32 != 0, has_res ? &rpre : nullptr);
     }
 }
 

@@ -126,26 +126,32 @@ __device__ __forceinline__ void sk_epilogue(const SkinnyArgs& p, float (&v0)[4],
         *reinterpret_cast<bf16x4*>(dp + p.pair_stride) = o2;
         return;
     }
-    if (p.gate != nullptr) {
+    // gate and residual are requested together, before either is used: in two dependent blocks (load gate, multiply, load residual,
+    // add) the epilogue was two memory round trips long
+    const bool has_g = p.gate != nullptr, has_r = p.residual != nullptr;
+    bf16x4 g0 = {}, g1 = {}, r0 = {}, r1 = {};
+    if (has_g) {
         const bf16_t* gp = p.gate + (int64_t)(mrow / p.gate_rpb) * p.gate_ld;
-        const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(gp + n0);
+        g0 = *reinterpret_cast<const bf16x4*>(gp + n0);
+        if (pair) g1 = *reinterpret_cast<const bf16x4*>(gp + n1);
+    }
+    if (has_r) {
+        const bf16_t* rp = p.residual + orow * p.ldr;
+        r0 = *reinterpret_cast<const bf16x4*>(rp + n0);
+        if (pair) r1 = *reinterpret_cast<const bf16x4*>(rp + n1);
+    }
+    if (has_g) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v0[e] = rbf(v0[e] * bf2f(g0[e]));
-        if (pair) {
-            const bf16x4 g1 = *reinterpret_cast<const bf16x4*>(gp + n1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v1[e] = rbf(v1[e] * bf2f(g1[e]));
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = rbf(v0[e] * bf2f(g0[e]));
+            if (pair) v1[e] = rbf(v1[e] * bf2f(g1[e]));
         }
     }
-    if (p.residual != nullptr) {
-        const bf16_t* rp = p.residual + orow * p.ldr;
-        const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(rp + n0);
+    if (has_r) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v0[e] = rbf(v0[e] + bf2f(r0[e]));
-        if (pair) {
-            const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(rp + n1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v1[e] = rbf(v1[e] + bf2f(r1[e]));
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = rbf(v0[e] + bf2f(r0[e]));
+            if (pair) v1[e] = rbf(v1[e] + bf2f(r1[e]));
         }
     }
     bf16x4 o1, o2;
