@@ -66,9 +66,8 @@ struct AttnArgs {
 // OP > 0: single pass for Sk <= 64 * OP keys — all OP key tiles (K and V) are staged into LDS at once, the logits of the whole
 // row stay in registers (OP x 4 x QT accumulators), so Q K^T is computed once and there is no per-tile barrier; OP = 0: the
 // general two-pass form (pass 1: row max / sum, pass 2: recompute the logits, P, P V).
-template <int NKS, int VC, int QT, int OP = 0, bool STG = false>
+template <int NKS, int VC, int QT, int OP = 0>
 __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const AttnArgs p) {
-    static_assert(!STG || (QT == 1 && OP == 0), "staggered pass 2: eight waves, two passes");
     constexpr int WAVES = 128 / (16 * QT);
     constexpr int OMT = VC / 16;
     constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
@@ -103,6 +102,9 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     const uint32_t ldk2 = (uint32_t)p.ldk * 2, ldv2 = (uint32_t)p.ldv * 2;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[row][32*ks + 8g .. +8] ----------------
+    // through a buffer descriptor: rows past the end / head-dim padding get an out-of-range offset and come back as zeros, so the
+    // KSTEPS loads are unconditional and in flight together (a guarded load is compiled as a branch with its own wait)
+    const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, (int)OOB, 0x00020000);
     bf16x8 qf[QT][KSTEPS];
 #pragma unroll
     for (int nt = 0; nt < QT; ++nt) {
@@ -110,11 +112,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int d = ks * 32 + g * 8;
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
-            if (r < p.rows && d < p.HD) v = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)r * p.ldq + d);
-            qf[nt][ks] = v;
+            const uint32_t off = (r < p.rows && d < p.HD) ? (uint32_t)r * (uint32_t)(p.ldq * 2) + (uint32_t)d * 2 : OOB;
+            qf[nt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, (int)off, 0, 0));
         }
     }
     // per-lane query codes (mask): the query position of folded row r is q0 + r / H
@@ -401,55 +400,6 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     }
 
     // ================================ pass 2: P and O = P V ===========================================================
-    if constexpr (STG) {
-        // Staggered form (eight waves = two groups of four, one wave of each per SIMD).  A tile is two barrier slots:
-        //   X(t) = [logits of tile t, mask, exp, P rounded and stored]   (MFMA 1/3 + the softmax VALU work + the P stores)
-        //   Y(t) = [O += P V of tile t]                                   (MFMA 2/3 + the transpose reads of V)
-        // Group 0 runs X(0) | Y(0) | X(1) | ..., group 1 the same sequence one slot later, so on every SIMD one wave is in its
-        // VALU / store heavy X while the other is in its MFMA / LDS heavy Y (measured: with all eight waves in lockstep the costs of
-        // the phases simply add up, KAI0_ATTN_ABLATE).  Slot 2t+1 holds Y(t) of group 0 and X(t) of group 1:
-        //  * both groups issue their DMA pieces of tile t+1 at the START of that slot (group 0 in front of Y(t), group 1 in front of
-        //    X(t)) into buffer (t+1) & 1, whose last readers — Y(t-1) of group 0 in slot 2t-1, of group 1 in slot 2t — retired their
-        //    reads before the barrier that opens slot 2t+1 (WAR);
-        //  * every wave waits for its own pieces at the END of slot 2t+1, in front of the barrier; the first reader of tile t+1 is
-        //    X(t+1) of group 0 in slot 2t+2 (RAW).  Group 1's two P stores of X(t) are younger than its pieces -> vmcnt(2 QT).
-        const int grp = wave >= WAVES / 2 ? 1 : 0;
-        stage(0, 0, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-        if (grp == 1) lds_barrier();  // one slot behind
-        for (int kt = 0; kt < ntiles; ++kt) {
-            const int buf = kt & 1;
-            const char* tk = smem + buf * STAGE;
-            const bool more = kt + 1 < ntiles && !(p.ablate & 8);
-            // ---- X(kt)
-            if (grp == 1 && more) stage(kt + 1, buf ^ 1, true);
-            int kc[4][4];
-            load_kcodes(kt, kc);
-            f32x4 s[4][QT];
-            if (p.ablate & 16) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < QT; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            } else
-            logits(tk, s);
-            finish_logits(kt, s, kc);
-            bf16x4 pb[4][QT];
-            make_p(kt, s, m_run, inv_l, pb);
-            if (grp == 1) {
-                if (p.P != nullptr && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            lds_barrier();
-            // ---- Y(kt)
-            if (grp == 0 && more) stage(kt + 1, buf ^ 1, true);
-            pv_tile(tk + K_BYTES, pb);
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-        }
-        if (grp == 0) lds_barrier();  // re-align the two groups
-    } else {
     stage(0, 0, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -473,7 +423,6 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
         if (p.P != nullptr && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-    }
     }
     }
     // zero the padding columns [64*ntiles, ldp) of P (none when ldp <= 64*ntiles) — the tiles above already wrote
@@ -510,6 +459,7 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE((int64_t)d->Sk * d->ldk * 2 < (int64_t)0x7FFF0000 && (int64_t)d->Sk * d->ldv * 2 < (int64_t)0x7FFF0000,
                  "kai0_attn_fwd: K/V span more than 2 GiB per batch entry");
     KAI0_REQUIRE(d->P == nullptr || (int64_t)d->rows * d->ldp * 2 < (int64_t)0x7FFF0000, "kai0_attn_fwd: P spans more than 2 GiB per batch entry");
+    KAI0_REQUIRE((int64_t)d->rows * d->ldq * 2 < (int64_t)0x7FFF0000, "kai0_attn_fwd: Q spans more than 2 GiB per batch entry");
     if (d->rows <= 0 || d->Sk <= 0) return 0;
     AttnArgs p;
     p.Q = (const bf16_t*)d->Q; p.K = (const bf16_t*)d->K; p.V = (const bf16_t*)d->V;
@@ -530,11 +480,11 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     const int batch = d->batch > 0 ? d->batch : 1;
     dim3 grid((d->rows + 127) / 128, batch, 1);
     hipStream_t s = (hipStream_t)stream;
-#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP, STG)                                                                          \
+#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP)                                                                          \
     do {                                                                                                          \
         constexpr int LDS = (OP > 0 ? OP : 2) * (NKS * 8192 + 64 * VC * 2) + 4 * 4096 + KC_LDS_MAX * 4;          \
         static bool attr_set = false;                                                                             \
-        auto kern = attn_fwd_kernel<NKS, VC, QT, OP, STG>;                                                             \
+        auto kern = attn_fwd_kernel<NKS, VC, QT, OP>;                                                             \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             KAI0_REQUIRE(e == hipSuccess, "kai0_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
@@ -545,20 +495,18 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     // KAI0_ATTN_QT=2: the former four-wave blocks; KAI0_ATTN_ONEPASS=0: always two passes (diagnostics)
     static const int qt = [] { const char* e = getenv("KAI0_ATTN_QT"); return e ? atoi(e) : 1; }();
     static const int onepass = [] { const char* e = getenv("KAI0_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
-    // KAI0_ATTN_STAGGER=1: the two wave groups of pass 2 one barrier slot apart (measured SLOWER: 1.095 vs 0.965 ms — the phases are
-    // latency-bound, two lockstep waves per SIMD already cover each other, and a slot lasts as long as its longer phase)
-    static const int stagger = [] { const char* e = getenv("KAI0_ATTN_STAGGER"); return e ? atoi(e) : 0; }();
+    // (Measured and rejected, round 3: the two wave groups of pass 2 one barrier slot apart — group 0 in [logits, softmax, P store]
+    // while group 1 is in [P V] — 1.095 against 0.965 ms: the phases are latency-bound, two lockstep waves per SIMD already cover
+    // each other, and a slot lasts as long as its longer phase.)
     if (d->HD <= 128) {
-        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0, false);
+        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0);
         // 256 keys = 4 resident tiles (144 KiB, one block per CU): wins when the grid is at most a round or two of the chip
         // (B = 1 inference: 26 -> 19 us); with thousands of blocks the two-pass form's two 80-KiB blocks per CU are as fast
-        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, false);
-        else if (stagger) KAI0_ATTN_LAUNCH(2, 128, 1, 0, true);
-        else KAI0_ATTN_LAUNCH(2, 128, 1, 0, false);
+        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4);
+        else KAI0_ATTN_LAUNCH(2, 128, 1, 0);
     } else {
-        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, false);
-        else if (stagger) KAI0_ATTN_LAUNCH(4, 256, 1, 0, true);
-        else KAI0_ATTN_LAUNCH(4, 256, 1, 0, false);
+        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0);
+        else KAI0_ATTN_LAUNCH(4, 256, 1, 0);
     }
 #undef KAI0_ATTN_LAUNCH
     return kai0_check_launch("kai0_attn_fwd");

@@ -250,3 +250,40 @@ def test_wgrad_ring_gemm_production_shape():
     print(f"TN ring 16384x2048x30976: rel-L2 {e:.3e} on {rows.numel()} rows")
     assert e < 4e-3
     assert torch.isfinite(dw.float()).all()
+
+
+def test_fullwidth_chunk_switches_agree(fw, monkeypatch):
+    """At the real widths (where the in-block denoise kernels, the step-seam kernel and the pair GEMM actually run): the chunk with
+    the modulation table recomputed per call is bit-identical to the cached one; with the six-launch step seam instead of
+    kai0_denoise_glue it differs by the round-off of the seam's two f32 dots (amplified by the bf16 roundings downstream); with gate GEMM + up GEMM instead of the pair GEMM it is bit-identical."""
+    from test_fullsize_gpu import _take
+
+    from kai0_amd import ops
+
+    m, d = fw["model"], dev()
+    m.eval()
+    try:
+        gobs, noise = _take(fw["gobs"], 1), fw["noise"][1:2].to(d)
+        ref = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        eng = m._engine
+        assert eng.glue and eng.cache_mods and eng.inblock and eng.decode_attn
+        monkeypatch.setenv("KAI0_INFER_CACHE_MODS", "0")
+        m.invalidate_inference_engine()
+        assert torch.equal(m.sample_actions(d, gobs, noise=noise, num_steps=10), ref)
+        monkeypatch.setenv("KAI0_INFER_GLUE", "0")
+        m.invalidate_inference_engine()
+        six = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        # (the two f32 dots of a seam sum in another order; a flipped bf16 rounding then travels through 18 layers x 10 steps:
+        # measured 4.4e-4, an order of magnitude inside the chunk's tolerance against the oracle)
+        assert not m._engine.glue and rel(six, ref) < 2e-3, rel(six, ref)
+        monkeypatch.delenv("KAI0_INFER_CACHE_MODS")
+        monkeypatch.delenv("KAI0_INFER_GLUE")
+        old = ops.set_geglu_pair(False)
+        try:
+            m.invalidate_inference_engine()
+            assert torch.equal(m.sample_actions(d, gobs, noise=noise, num_steps=10), ref)
+        finally:
+            ops.set_geglu_pair(old)
+    finally:
+        m.invalidate_inference_engine()
+        m.train()

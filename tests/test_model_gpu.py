@@ -507,3 +507,40 @@ def test_train_loop_debug_pi05_resume_is_exact(tmp_path):
     for a, b in zip(rest, full[4:]):
         assert a["loss"] == b["loss"] and a["grad_norm"] == b["grad_norm"] and a["learning_rate"] == b["learning_rate"], (a, b)
     print("debug_pi05 loss curve", [round(r["loss"], 5) for r in full], "resumed", [round(r["loss"], 5) for r in rest])
+
+
+def test_round3_switches_leave_results_unchanged(pair, monkeypatch):
+    """The alternative paths behind the round-3 switches stay tested configurations: the GeGLU pair GEMM (act 6) vs gate GEMM + up GEMM
+    (loss bit-identical), and the action chunk with the per-engine modulation table / one-launch step seams vs recomputing the
+    modulations in every call / the six-launch seam (bit-identical for the table; f32 round-off for the seam's two dots)."""
+    from kai0_amd import ops
+
+    m, dev = pair["model"], pair["dev"]
+    args = (pair["gobs"], pair["actions"].to(dev))
+    kw = dict(noise=pair["noise"].to(dev), time=pair["time"].to(dev))
+    with torch.no_grad():
+        base = m(*args, **kw)
+        old = ops.set_geglu_pair(False)
+        try:
+            two = m(*args, **kw)
+        finally:
+            ops.set_geglu_pair(old)
+    assert torch.equal(base, two)
+    m.eval()
+    try:
+        noise = pair["noise"].to(dev)
+        ref = m.sample_actions(dev, pair["gobs"], noise=noise, num_steps=10)
+        assert m._engine.glue and m._engine.cache_mods
+        monkeypatch.setenv("KAI0_INFER_CACHE_MODS", "0")
+        m.invalidate_inference_engine()
+        a = m.sample_actions(dev, pair["gobs"], noise=noise, num_steps=10)
+        assert not m._engine.cache_mods and torch.equal(a, ref)
+        monkeypatch.setenv("KAI0_INFER_GLUE", "0")
+        m.invalidate_inference_engine()
+        b = m.sample_actions(dev, pair["gobs"], noise=noise, num_steps=10)
+        assert not m._engine.glue and rel(b, ref) < 1e-5
+    finally:
+        monkeypatch.delenv("KAI0_INFER_CACHE_MODS", raising=False)
+        monkeypatch.delenv("KAI0_INFER_GLUE", raising=False)
+        m.invalidate_inference_engine()
+        m.train()
