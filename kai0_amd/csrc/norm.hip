@@ -38,18 +38,24 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
     const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
     const int nchunk = D >> 3;
+    // plain RMSNorm: the weight does not depend on the row — requested once, together with the first row (not behind its reduction);
+    // the row itself with a clamped chunk index instead of a guard (see layernorm_fwd_kernel)
+    float wv[MAXC][8];
+    if constexpr (!ADA) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) loadf8(w + min(c * 64 + lane, nchunk - 1) * 8, wv[c]);
+    }
     for (int64_t row = wg; row < rows; row += nw) {
         const bf16_t* xr = x + row * D;
         float xv[MAXC][8];
         float ss = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ci = c * 64 + lane;
-            if (ci < nchunk) {
-                load8(xr + ci * 8, xv[c]);
+        for (int c = 0; c < MAXC; ++c) load8(xr + min(c * 64 + lane, nchunk - 1) * 8, xv[c]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss += xv[c][e] * xv[c][e];
-            }
+        for (int c = 0; c < MAXC; ++c) {
+            const bool live = c * 64 + lane < nchunk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += live ? xv[c][e] * xv[c][e] : 0.f;
         }
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss / (float)D + eps);
@@ -67,10 +73,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] * rstd) * (1.0f + sc[e]) + sh[e];
                 } else {
-                    float wv[8];
-                    loadf8(w + ci * 8, wv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] * rstd) * (1.0f + wv[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] * rstd) * (1.0f + wv[c][e]);
                 }
                 store8(y + row * D + ci * 8, o);
                 if constexpr (ADA) {
@@ -498,41 +502,45 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
     const int nchunk = D >> 3;
+    // weight and bias do not depend on the row: requested once, with the first row's data (not behind its two reductions); all loads
+    // with a clamped chunk index instead of a guard (a guarded load is a branch with its own wait: at B = 1, one row per wave, the
+    // kernel was four dependent round trips long)
+    float wv[MAXC][8], bv[MAXC][8];
+    bool live[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ci = c * 64 + lane;
+        live[c] = ci < nchunk;
+        const int cc = min(ci, nchunk - 1);
+        load8(w + cc * 8, wv[c]);
+        load8(bsh + cc * 8, bv[c]);
+    }
     for (int64_t row = wg; row < rows; row += nw) {
         float xv[MAXC][8];
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ci = c * 64 + lane;
-            if (ci < nchunk) {
-                load8(x + row * D + ci * 8, xv[c]);
+        for (int c = 0; c < MAXC; ++c) load8(x + row * D + min(c * 64 + lane, nchunk - 1) * 8, xv[c]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += xv[c][e];
-            }
-        }
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += live[c] ? xv[c][e] : 0.f;
         const float mean = wave_sum(s) / (float)D;
         float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ci = c * 64 + lane;
-            if (ci < nchunk) {
+        for (int c = 0; c < MAXC; ++c)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = xv[c][e] - mean;
-                    v += d * d;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv[c][e] - mean;
+                v += live[c] ? d * d : 0.f;
             }
-        }
         const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ci = c * 64 + lane;
             if (ci < nchunk) {
-                float wv[8], bv[8], o[8];
-                load8(w + ci * 8, wv);
-                load8(bsh + ci * 8, bv);
+                float o[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] - mean) * rstd * wv[e] + bv[e];
+                for (int e = 0; e < 8; ++e) o[e] = (xv[c][e] - mean) * rstd * wv[c][e] + bv[c][e];
                 store8(y + row * D + ci * 8, o);
             }
         }
