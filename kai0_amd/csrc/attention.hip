@@ -66,9 +66,13 @@ struct AttnArgs {
 // OP > 0: single pass for Sk <= 64 * OP keys — all OP key tiles (K and V) are staged into LDS at once, the logits of the whole
 // row stay in registers (OP x 4 x QT accumulators), so Q K^T is computed once and there is no per-tile barrier; OP = 0: the
 // general two-pass form (pass 1: row max / sum, pass 2: recompute the logits, P, P V).
-template <int NKS, int VC, int QT, int OP = 0>
-__global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const AttnArgs p) {
-    constexpr int WAVES = 128 / (16 * QT);
+// RB = query rows per block (128; 64: four waves, ONE staging buffer, 80 KiB of LDS -> two independent blocks per CU that cover each
+// other's DMA waits and softmax chains instead of eight lockstep waves).
+template <int NKS, int VC, int QT, int OP = 0, int RB = 128>
+__global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int WAVES = RB / (16 * QT);
+    constexpr int NST = RB == 64 ? 1 : 2;  // staging buffers of the two-pass form
+    static_assert(RB == 128 || (RB == 64 && OP == 0 && QT == 1), "64-row blocks: two passes, one 16-row tile per wave");
     constexpr int OMT = VC / 16;
     constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
     constexpr int K_BYTES = NKS * 8192;             // NKS x [64 keys][64 d] bf16
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     constexpr int NVP = (64 / V_RPP) / WAVES;       // V DMA pieces per wave per tile
     static_assert(NKP >= 1 && NVP >= 1, "too many waves for this tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* pbuf_all = smem + (OP > 0 ? OP : 2) * STAGE;  // WAVES x [16 QT rows][64 keys] bf16 (P transposition scratch)
+    char* pbuf_all = smem + (OP > 0 ? OP : NST) * STAGE;  // WAVES x [16 QT rows][64 keys] bf16 (P transposition scratch)
     int* kc_lds = reinterpret_cast<int*>(pbuf_all + WAVES * QT * 2048);  // key codes of all keys (see load_kcodes)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Pb, 0, (int)OOB, 0x00020000);
-    const int row0 = blockIdx.x * 128 + wave * (16 * QT);   // first query row of this wave
+    const int row0 = blockIdx.x * RB + wave * (16 * QT);   // first query row of this wave
     const int ntiles = (p.Sk + 63) / 64;
     const uint32_t ldk2 = (uint32_t)p.ldk * 2, ldv2 = (uint32_t)p.ldv * 2;
 
@@ -355,8 +359,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     for (int kt = 0; kt < ((p.ablate & 2) ? 0 : ntiles); ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, false);
+        const int buf = NST == 2 ? (kt & 1) : 0;
+        if (NST == 2 && kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, false);
         int kc[4][4];
         load_kcodes(kt, kc);
         f32x4 s[4][QT];
@@ -379,6 +383,10 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
                 l_run[nt] = acc;
                 m_run[nt] = mn;
             }
+        }
+        if (NST == 1) {  // one buffer: every wave is done reading tile kt before tile kt + 1 overwrites it
+            lds_barrier();
+            if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, 0, false);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
@@ -404,8 +412,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, true);
+        const int buf = NST == 2 ? (kt & 1) : 0;
+        if (NST == 2 && kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, true);
         const char* tk = smem + buf * STAGE;
         int kc[4][4];
         load_kcodes(kt, kc);
@@ -419,9 +427,15 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, 1) void attn_fwd_kernel(const
         logits(tk, s);
         finish_logits(kt, s, kc);
         emit_tile(kt, tk + K_BYTES, s, m_run, inv_l);
+        if (NST == 1) {
+            lds_barrier();
+            if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, 0, true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the P stores are older than these pieces)
+        } else {
         // the DMA of tile kt+1 (issued at the top of this iteration) must have landed; the P stores issued after it may fly
         if (p.P != nullptr && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         lds_barrier();
     }
     }
@@ -478,19 +492,21 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     const int kc_keys = ((d->Sk + 63) / 64) * 64;
     p.kc_lds_keys = (kc_lds && kc_keys <= KC_LDS_MAX) ? kc_keys : 0;  // longer key ranges read their codes from global
     const int batch = d->batch > 0 ? d->batch : 1;
-    dim3 grid((d->rows + 127) / 128, batch, 1);
+    static const int rb64 = [] { const char* e = getenv("KAI0_ATTN_RB64"); return e ? atoi(e) : 0; }();
+    const bool small = rb64 && d->HD > 128;  // (joint attention only)
+    dim3 grid((d->rows + (small ? 63 : 127)) / (small ? 64 : 128), batch, 1);
     hipStream_t s = (hipStream_t)stream;
-#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP)                                                                          \
+#define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP, RB)                                                                          \
     do {                                                                                                          \
-        constexpr int LDS = (OP > 0 ? OP : 2) * (NKS * 8192 + 64 * VC * 2) + 4 * 4096 + KC_LDS_MAX * 4;          \
+        constexpr int LDS = (OP > 0 ? OP : (RB == 64 ? 1 : 2)) * (NKS * 8192 + 64 * VC * 2) + (RB / 32) * 4096 + KC_LDS_MAX * 4; \
         static bool attr_set = false;                                                                             \
-        auto kern = attn_fwd_kernel<NKS, VC, QT, OP>;                                                             \
+        auto kern = attn_fwd_kernel<NKS, VC, QT, OP, RB>;                                                             \
         if (!attr_set) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
             KAI0_REQUIRE(e == hipSuccess, "kai0_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL(kern, grid, dim3(128 / (16 * QT) * 64), LDS, s, p);                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(RB / (16 * QT) * 64), LDS, s, p);                                    \
     } while (0)
     // KAI0_ATTN_QT=2: the former four-wave blocks; KAI0_ATTN_ONEPASS=0: always two passes (diagnostics)
     static const int qt = [] { const char* e = getenv("KAI0_ATTN_QT"); return e ? atoi(e) : 1; }();
@@ -499,14 +515,15 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     // while group 1 is in [P V] — 1.095 against 0.965 ms: the phases are latency-bound, two lockstep waves per SIMD already cover
     // each other, and a slot lasts as long as its longer phase.)
     if (d->HD <= 128) {
-        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0);
+        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0, 128);
         // 256 keys = 4 resident tiles (144 KiB, one block per CU): wins when the grid is at most a round or two of the chip
         // (B = 1 inference: 26 -> 19 us); with thousands of blocks the two-pass form's two 80-KiB blocks per CU are as fast
-        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4);
-        else KAI0_ATTN_LAUNCH(2, 128, 1, 0);
+        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
+        else KAI0_ATTN_LAUNCH(2, 128, 1, 0, 128);
     } else {
-        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0);
-        else KAI0_ATTN_LAUNCH(4, 256, 1, 0);
+        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, 128);
+        else if (small) KAI0_ATTN_LAUNCH(4, 256, 1, 0, 64);
+        else KAI0_ATTN_LAUNCH(4, 256, 1, 0, 128);
     }
 #undef KAI0_ATTN_LAUNCH
     return kai0_check_launch("kai0_attn_fwd");
