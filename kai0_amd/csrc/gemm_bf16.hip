@@ -255,7 +255,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
-    static_assert(SCH == 0 || (PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4), "quadrant schedule: 256x256x64");
+    static_assert(SCH == 0 || (PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4) || (SCH == 3 && PP && NS == 4), "quadrant schedule: 256x256x64");
     static_assert(NS >= 2 && (!PP || NS == 2 || (NS == 4 && BKT == 32)), "stages");
     static_assert(BKT == 64 || BKT == 32, "K-tile depth");
     constexpr int BK = BKT;
@@ -479,12 +479,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
 #pragma unroll
             for (int t = 0; t < MT; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + t * 16, 0);
             uint32_t poff[NP];
+            if constexpr (SCH == 0) {
 #pragma unroll
-            for (int pi = 0; pi < NP; ++pi) poff[pi] = p.ablate == 1 ? OOB : piece_off(u + 3, pi);
+                for (int pi = 0; pi < NP; ++pi) poff[pi] = p.ablate == 1 ? OOB : piece_off(u + 3, pi);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            piece_issue(poff[0], pslot, 0);
-            piece_issue(poff[1], pslot, 1);
-            if (grp == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (SCH == 0) {
+                piece_issue(poff[0], pslot, 0);
+                piece_issue(poff[1], pslot, 1);
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                // SCH == 3: all four pieces of u+3 go out between the MFMA rows (a piece costs its wave ~60 cycles there against
+                // 100-180 next to the fragment reads); group 1 therefore ends L(u) with only u+2's four pieces younger than u+1's
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
             lds_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -492,9 +500,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                if (i == 2 || i == 5) {
+                if (SCH == 0 && (i == 2 || i == 5)) {
                     __builtin_amdgcn_sched_barrier(0);
                     piece_issue(poff[i == 2 ? 2 : 3], pslot, i == 2 ? 2 : 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (SCH == 3 && (i & 1) == 0) {  // (the offset arithmetic sits in the MFMA shadow too)
+                    __builtin_amdgcn_sched_barrier(0);
+                    poff[i >> 1] = p.ablate == 1 ? OOB : piece_off(u + 3, i >> 1);
+                    piece_issue(poff[i >> 1], pslot, i >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill pieces must land before the slabs reuse LDS
         if (grp == 0) lds_barrier();  // re-align the two groups
         lds_barrier();
-    } else if constexpr (PP && SCH != 0) {
+    } else if constexpr (PP && NS == 2 && SCH != 0) {
         // Quadrant schedule.  Wave (wm, wn) owns rows wm*128 + [0, 128), columns wn*64 + [0, 64) of the tile; half-operand
         // A_a = its rows a*64 + [0, 64) (for both wm: 128 tile rows), B_b = its columns b*32 + [0, 32) (for all four wn: 128 tile
         // columns); 16 KiB = 16 DMA pieces each, two per wave.  Tile t (LDS slot t & 1) runs the quadrants
@@ -765,7 +779,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int64_t vz = z1 * p.rv_s1 + z2 * p.rv_s2;
     // quadrant schedule with a contraction-strided operand: that operand's sub-tiles are interleaved (see the schedule)
-    constexpr bool ILM = SCH != 0 && !A_KC, ILN = SCH != 0 && !B_KC;
+    constexpr bool ILM = (SCH == 1 || SCH == 2) && !A_KC, ILN = (SCH == 1 || SCH == 2) && !B_KC;
     const int ccol = ILN ? n0 + ((lane & 7) >> 2) * 128 + wn * 32 + ((lane & 7) & 3) * 8 : n0 + wn * 64 + (lane & 7) * 8;
     auto row_base = [&](int h) { return ILM ? m0 + h * 128 + wm * 64 : m0 + wm * (MT * 16) + h * 64; };
     // 8-wide column groups: when N % 8 != 0 the last group's extra columns hold exact zeros (their B rows are
@@ -1229,7 +1243,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
     else if (forced == 9) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
     else if (forced == 10) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);
-    else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);
+    else if (forced == 11 && !d->a_kc && !d->b_kc) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);  // the former ring: two of a sub-tile's four DMA pieces in the load slot
+    // ring with every DMA piece (and its offset arithmetic) between the MFMA rows: +0.9 % over two pieces per slot kind on the TN shapes
+    else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32, 3>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     // NT: quadrant schedule (measured +6..10 % over the two-buffer ping-pong on every pi0.5 shape, 1.37 PFLOP/s at 8192^3);
     // KAI0_GEMM_CFG=5 forces the former for all layouts
