@@ -399,7 +399,7 @@ def main():
             allr = [mine]
         by = eng.comm_bytes_per_step()
         comm = {
-            "mode": eng.mode, "buckets": len(eng.buckets), "bucket_mb": max(b.numel * b.flat_param.element_size() for b in eng.buckets) / 2**20,
+            "mode": eng.mode, "rs_algo": eng.rs_algo, "buckets": len(eng.buckets), "bucket_mb": max(b.numel * b.flat_param.element_size() for b in eng.buckets) / 2**20,
             "comm_exposed_ms_per_rank": [float(t[0]) for t in allr],
             "all_gather_wait_ms_per_rank": [float(t[1]) for t in allr],
             "reduce_scatter_wait_ms_per_rank": [float(t[2]) for t in allr],
@@ -408,7 +408,7 @@ def main():
             "bytes_per_rank_per_step": by,
             "xgmi_gbs_if_fully_overlapped": by["total"] / 1e9 / (max(float(t[4]) for t in allr) / 1e3) if by["total"] else 0.0,
             "rccl_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE",
-                                                    "RCCL_MSCCLPP_ENABLE") if k in os.environ},
+                                                    "RCCL_MSCCLPP_ENABLE", "KAI0_RS_ALGO") if k in os.environ},
             "measured": f"events on the compute stream around every collective wait, {timer_steps} steps after the timed region",
         }  # fmt: skip
     # Extra (not the headline value): the same step with the prompt cut to the longest valid prompt of the batch

@@ -419,6 +419,12 @@ int kai0_denoise_glue(const void* xs, const float* mod, int64_t mod_ld, int rows
  * sumsq: out[0] += sum(g^2) over a bf16 or f32 buffer (caller zeroes out).  scratch: 4096 floats for the per-block partials,
  * which a second launch adds in a fixed order (reproducible gradient norm; no atomics). */
 int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, float* scratch, kai0_stream_t stream);
+/* dst[i] = sum_j src[j * chunk_stride + i] (j = 0 .. chunks-1 in that order, f32 accumulation, one rounding to the buffer's
+ * dtype: bf16 or f32).  The reduction half of the all-pairs gradient reduce-scatter (kai0_amd.sharded, rs_algo "alltoall"): the
+ * all-to-all delivers every peer's copy of this rank's slice over that peer's own xGMI link, this kernel adds them — what the
+ * reduction inside DistributedDataParallel's all-reduce does (train_pytorch.py:440-447), without a rounding per ring hop.
+ * n and chunk_stride multiples of 8 (bf16) / 4 (f32) elements, buffers 16-byte aligned. */
+int kai0_sum_chunks(const void* src, int is_f32, int chunks, int64_t chunk_stride, int64_t n, void* dst, kai0_stream_t stream);
 /* Fused AdamW on a flat shard: master/m/v f32, grad bf16 or f32, writes the bf16 (or f32) model copy.
  * clip_coef is read from device memory (coef[0]) so the step stays graph/stream ordered:
  *   g = grad * coef[0]; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

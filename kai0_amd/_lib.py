@@ -141,6 +141,7 @@ _PROTOS: dict[str, list] = {
     "kai0_euler_step": [c_p, c_p, c_f, c_i64, c_p],
     "kai0_denoise_glue": [c_p, c_p, c_i64, c_i, c_f, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
     "kai0_sumsq": [c_p, c_i, c_i64, c_p, c_p, c_p],
+    "kai0_sum_chunks": [c_p, c_i, c_i, c_i64, c_i64, c_p, c_p],
     "kai0_clip_coef": [c_p, c_f, c_p, c_p, c_p],
     "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
 }  # fmt: skip

@@ -57,6 +57,40 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
     coef[0] = c < 1.0f ? c : 1.0f;
 }
 
+// dst[i] = round(sum_j src[j * stride + i]), j = 0 .. chunks-1 in that order, summed in f32: the local half of the all-pairs
+// reduce-scatter (sharded.py rs_algo "alltoall": every peer's copy of this rank's gradient slice arrives over its own xGMI
+// link, the sum happens here, once, instead of hop by hop around a ring with a bf16 rounding per hop)
+template <bool F32>
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const void* __restrict__ src, int chunks, int64_t stride, int64_t n,
+                                                         void* __restrict__ dst) {
+    constexpr int V = F32 ? 4 : 8;
+    const int64_t nv = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int j = 0; j < chunks; ++j) {
+            if constexpr (F32) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + j * stride + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            } else {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(src) + j * stride + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+            }
+        }
+        if constexpr (F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dst) + i * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(dst) + i * 8) = o;
+        }
+    }
+}
+
 template <bool GF32, bool PF32>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const void* __restrict__ grad, void* __restrict__ param, int64_t n,
@@ -101,6 +135,20 @@ KAI0_API int kai0_sumsq(const void* g, int g_f32, int64_t n, float* out, float* 
     else hipLaunchKernelGGL((sumsq_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
     hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, grid, out);
     return kai0_check_launch("kai0_sumsq");
+}
+
+KAI0_API int kai0_sum_chunks(const void* src, int is_f32, int chunks, int64_t chunk_stride, int64_t n, void* dst,
+                            kai0_stream_t stream) {
+    if (n <= 0) return 0;
+    KAI0_REQUIRE(src && dst && chunks >= 1, "kai0_sum_chunks: null buffer or no chunks");
+    const int V = is_f32 ? 4 : 8;
+    KAI0_REQUIRE((n % V) == 0 && (chunk_stride % V) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                 "kai0_sum_chunks: n=%lld, stride=%lld must be multiples of %d elements and the buffers 16-byte aligned",
+                 (long long)n, (long long)chunk_stride, V);
+    const int grid = opt_grid(n / V);
+    if (is_f32) hipLaunchKernelGGL((sum_chunks_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src, chunks, chunk_stride, n, dst);
+    else hipLaunchKernelGGL((sum_chunks_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src, chunks, chunk_stride, n, dst);
+    return kai0_check_launch("kai0_sum_chunks");
 }
 
 KAI0_API int kai0_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, kai0_stream_t stream) {

@@ -54,6 +54,13 @@ def sumsq_accumulate_(grad, out):
     _lib.call("kai0_sumsq", grad.data_ptr(), int(grad.dtype == F32), grad.numel(), out.data_ptr(), scratch.data_ptr(), _stream())
 
 
+def sum_chunks_(src, chunks: int, out):
+    """out[i] = sum_j src[j * out.numel() + i] in f32, one rounding (the local half of the all-pairs reduce-scatter)."""
+    n = out.numel()
+    assert src.dtype == out.dtype and src.numel() == chunks * n and src.is_contiguous() and out.is_contiguous()
+    _lib.call("kai0_sum_chunks", src.data_ptr(), int(src.dtype == F32), int(chunks), n, n, out.data_ptr(), _stream())
+
+
 def clip_coef_(sumsq, max_norm: float, coef, norm_out):
     _lib.call("kai0_clip_coef", sumsq.data_ptr(), float(max_norm), coef.data_ptr(), norm_out.data_ptr(), _stream())
 

@@ -25,6 +25,11 @@ bucket's reduce-scatter is issued from inside backward the moment its last gradi
 write straight into the flat gradient buffer: no copy, no autograd accumulation).  SUM collectives only (the loss is
 scaled by 1/N), so the gloo tests on CPU drive exactly the call path RCCL runs.
 
+Gradient reduce-scatter, two forms (`rs_algo`, env KAI0_RS_ALGO): "rccl" — the library's `reduce_scatter_tensor` (default); "alltoall"
+— the all-pairs form for the fully connected xGMI mesh: one `all_to_all_single` sends slice j of the bucket straight to rank j
+(every link of the GPU busy at once, one hop), `ShardOps.sum_chunks` (kai0_sum_chunks) adds the N received copies of the own
+slice in f32 with one rounding.  Everything around it (issue from inside backward, staging, waits, bookkeeping) is shared.
+
 Evidence for the first multi-GPU run (`comm_profile = True`, read with `comm_report()`): every place where the compute
 stream has to wait for a collective (a parameter gather in pre_forward / pre_backward, the reduce-scatters and the norm
 all-reduce in step()) is bracketed by two events on the compute stream, so `comm_exposed_ms` is the time the chip sat in those
@@ -58,6 +63,11 @@ class HipShardOps:
         from .optim import clip_coef_
 
         clip_coef_(sumsq, max_norm, coef, norm)
+
+    def sum_chunks(self, src, chunks, out):
+        from .optim import sum_chunks_
+
+        sum_chunks_(src, chunks, out)
 
     def adamw(self, master, m, v, grad, param, *, lr, beta1, beta2, eps, wd, step, clip_coef):
         from .optim import adamw_step_
@@ -112,6 +122,21 @@ class _Bucket:
         self.exp_avg_sq = torch.zeros(self.shard, dtype=F32, device=sl.device)
 
 
+class _AllPairsReduce:
+    """In-flight all-pairs reduce-scatter of one bucket: the all-to-all that delivers every peer's copy of this rank's
+    gradient slice, then (at wait time, on the waiting stream) the f32 sum of the `world` received slices into the shard."""
+
+    def __init__(self, work, recv, bucket, world, ops):
+        self.work, self.recv, self.bucket, self.world, self.ops = work, recv, bucket, world, ops
+
+    def wait(self):
+        self.work.wait()
+        self.ops.sum_chunks(self.recv, self.world, self.bucket.grad_shard)
+        if self.recv.is_cuda:  # allocated under the stream that issued the collective, read here under the waiting one
+            self.recv.record_stream(torch.cuda.current_stream(self.recv.device))
+        self.recv = None
+
+
 class _BackwardMark(torch.autograd.Function):
     """Identity on a unit's outputs whose backward tells the engine that the unit's backward is about to start
     (fsdp: its parameters are gathered again, the bucket before it is prefetched)."""
@@ -130,11 +155,15 @@ class _BackwardMark(torch.autograd.Function):
 class ShardedDataParallel:
     def __init__(self, params, *, world_size: int, rank: int, group=None, ops=None, betas=(0.9, 0.95), eps=1e-8,
                  weight_decay=1e-10, max_grad_norm=1.0, bucket_bytes: int = 512 << 20, units=None, mode: str = "zero2",
-                 prefetch: int = 1, sync_params: bool = True):  # fmt: skip
+                 prefetch: int = 1, sync_params: bool = True, rs_algo: str | None = None):  # fmt: skip
         """`params`: parameters, or (name, parameter) pairs (names make the checkpoint world-size independent).
         `units`: [(unit name, [parameters])] in forward-use order; parameters not listed form a last unit "rest"."""
         if mode not in ("zero2", "fsdp"):
             raise ValueError(f"mode must be 'zero2' or 'fsdp', got {mode!r}")
+        rs_algo = rs_algo or os.environ.get("KAI0_RS_ALGO", "rccl")
+        if rs_algo not in ("rccl", "alltoall"):
+            raise ValueError(f"rs_algo must be 'rccl' or 'alltoall', got {rs_algo!r}")
+        self.rs_algo = rs_algo
         self.world, self.rank, self.group = world_size, rank, group
         self.ops = ops or HipShardOps()
         self.betas, self.eps, self.wd, self.max_grad_norm = betas, eps, weight_decay, max_grad_norm
@@ -239,6 +268,14 @@ class ShardedDataParallel:
         if not self.collectives:
             return None  # grad_shard aliases flat_grad
         self._join_streams()  # the bucket's gradients were written under two streams (ops.side_stream): behind both
+        if self.rs_algo == "alltoall":
+            # all-pairs form for the fully connected xGMI mesh: slice j of the flat gradients goes straight to rank j over the
+            # link the two share (N-1 links busy at once, one hop), and the N copies of the own slice are summed locally in f32
+            # (kai0_sum_chunks) — the library's ring moves the same (N-1)/N bytes per rank but in N-1 dependent hops, each bound by
+            # ONE link and each rounding the running sum to bf16.  Costs a receive buffer of the bucket's size while in flight.
+            recv = torch.empty_like(b.flat_grad)
+            work = dist.all_to_all_single(recv, b.flat_grad, group=self.group, async_op=True)
+            return _AllPairsReduce(work, recv, b, self.world, self.ops)
         return dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _join_streams(self):

@@ -698,6 +698,21 @@ def test_adamw_and_clip(ops):
         assert torch.equal(p.detach(), m.to(p.dtype))
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("chunks,n", [(1, 4096), (4, 1024 * 37), (8, 8 * 250_001)])
+def test_sum_chunks_is_an_f32_sum_with_one_rounding(ops, dtype, chunks, n):
+    """kai0_sum_chunks (the local half of the all-pairs reduce-scatter, sharded.py): bit-exact against the f32 sum in slice order."""
+    from kai0_amd.optim import sum_chunks_
+
+    src = rnd(chunks, n, dtype=dtype, seed=3) * 7
+    out = torch.empty(n, dtype=dtype, device=dev())
+    sum_chunks_(src.reshape(-1), chunks, out)
+    acc = torch.zeros(n, dtype=F32, device=dev())
+    for j in range(chunks):
+        acc += src[j].float()
+    assert torch.equal(out, acc.to(dtype))
+
+
 # ------------------------------------------------------------------------------------ skinny (denoise) GEMM
 @pytest.mark.parametrize("M,K,N", [(50, 1024, 1024), (100, 1024, 512), (7, 512, 64)])
 def test_skinny_plain_gate_residual(ops, M, K, N):

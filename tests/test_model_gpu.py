@@ -388,12 +388,13 @@ def test_policy_infer_over_the_hip_model(tmp_path):
     assert err < 2e-2
 
 
-@pytest.mark.parametrize("mode", ["zero2", "fsdp"])
-def test_trainer_with_rccl_collectives_equals_collective_free_engine(pair, mode, monkeypatch):
+@pytest.mark.parametrize("mode,rs_algo", [("zero2", "rccl"), ("fsdp", "rccl"), ("zero2", "alltoall"), ("fsdp", "alltoall")])
+def test_trainer_with_rccl_collectives_equals_collective_free_engine(pair, mode, rs_algo, monkeypatch):
     """The RCCL call pattern of both sharding modes (SUM reduce-scatter issued from inside backward, all-gather awaited unit by
     unit / just-in-time gather + release, async work handles) on the ONE GPU of the test box: RCCL refuses two ranks on one
     device, so a 1-rank group runs the collectives as self-copies; results must equal the collective-free engine bit for
-    bit.  (world-2 logic: tests/test_sharded_cpu.py on gloo — the same code path.)"""
+    bit.  (world-2 logic: tests/test_sharded_cpu.py on gloo — the same code path.)  rs_algo "alltoall": the all-pairs
+    reduce-scatter (RCCL all_to_all_single + kai0_sum_chunks)."""
     import torch.distributed as dist
     from tiny import build_pair
 
@@ -409,12 +410,14 @@ def test_trainer_with_rccl_collectives_equals_collective_free_engine(pair, mode,
         tr = Trainer(model, world_size=1, rank=0, peak_lr=1e-3, warmup_steps=0, decay_steps=10, end_lr=1e-3, clip_norm=1.0,
                      bucket_bytes=1 << 16, mode=mode)  # fmt: skip
         assert tr.engine.collectives == collective and tr.engine.mode == (mode if collective else "zero2")
+        assert not collective or tr.engine.rs_algo == rs_algo
         losses = [float(tr.train_step(*args, **kw)) for _ in range(3)]
         tr.params_ready()
         torch.cuda.synchronize()
         return losses, [p.detach().clone() for p in model.parameters()], float(tr.last_grad_norm)
 
     base = run(False)
+    monkeypatch.setenv("KAI0_RS_ALGO", rs_algo)
     monkeypatch.setenv("KAI0_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29617")

@@ -23,6 +23,9 @@ class TorchShardOps:
         norm.copy_(sumsq.sqrt())
         coef.copy_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
 
+    def sum_chunks(self, src, chunks, out):
+        out.copy_(src.view(chunks, -1).float().sum(0).to(out.dtype))
+
     def adamw(self, master, m, v, grad, param, *, lr, beta1, beta2, eps, wd, step, clip_coef):
         g = grad.float() * (clip_coef if clip_coef is not None else 1.0)
         m.mul_(beta1).add_(g, alpha=1 - beta1)
@@ -149,15 +152,17 @@ def test_sharded_engine_matches_single_process_adamw():
 
 
 # --------------------------------------------------------------------------------------- unit hooks: zero2 and fsdp
-def _worker_units(rank, world, port, tmp, mode, prefetch=1):
+def _worker_units(rank, world, port, tmp, mode, prefetch=1, rs_algo="rccl"):
     _init(rank, world, port)
     torch.set_num_threads(1)
     from kai0_amd.sharded import ShardedDataParallel
 
     model, ref = UnitStack(seed=3), UnitStack(seed=3)
     eng = ShardedDataParallel(list(model.named_parameters()), world_size=world, rank=rank, ops=TorchShardOps(), weight_decay=0.0,
-                              max_grad_norm=1.0, bucket_bytes=1500, units=model.sharding_units(), mode=mode, prefetch=prefetch)  # fmt: skip
+                              max_grad_norm=1.0, bucket_bytes=1500, units=model.sharding_units(), mode=mode, prefetch=prefetch,
+                              rs_algo=rs_algo)  # fmt: skip
     model.hooks = eng
+    assert eng.rs_algo == rs_algo
     model.blocks[1].weight._kai0_grad_accumulates = True  # (a producer that accumulates: its slice is re-zeroed after every step)
     assert eng.mode == mode and len(eng.groups) >= 3
     assert any(len(ids) == 2 for ids in eng.groups)  # a bf16 and an f32 bucket in one group
@@ -222,6 +227,34 @@ def test_unit_hooks_gather_per_unit(mode):
 def test_world4_uneven_last_bucket(mode):
     """VERDICT r2 #6d: four ranks, bucket sizes that differ (and are padded to 4 x 256 elements), prefetch 2 in fsdp mode."""
     _spawn(_worker_units, 4, mode, 2)
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world,mode", [(2, "zero2"), (4, "fsdp"), (4, "zero2")])
+def test_all_pairs_reduce_scatter(world, mode):
+    """rs_algo "alltoall": slice j of every rank's flat gradients goes to rank j in one all-to-all, the copies are summed locally in
+    f32 (kai0_sum_chunks on the GPU; its torch restatement here) — same updates as the library reduce-scatter, staging included."""
+    _spawn(_worker_units, world, mode, 2 if mode == "fsdp" else 1, "alltoall")
+
+
+def test_all_pairs_reduce_is_one_rounding():
+    """The local sum accumulates the peers' bf16 slices in f32 and rounds once (a ring rounds the running sum at every hop)."""
+    from kai0_amd.sharded import _AllPairsReduce
+
+    class Done:
+        def wait(self):
+            pass
+
+    class B:
+        grad_shard = torch.zeros(8, dtype=torch.bfloat16)
+
+    recv = torch.tensor([[256.0] * 8, [1.0] * 8, [1.0] * 8, [1.0] * 8], dtype=torch.bfloat16).reshape(-1)
+    _AllPairsReduce(Done(), recv, B, 4, TorchShardOps()).wait()
+    assert float(B.grad_shard[0]) == 260.0  # 259 in f32 -> 260 in bf16 (ties-to-even of 259 at spacing 2); hop by hop: 256 + 1 = 256 three times
+    acc = torch.tensor(256.0, dtype=torch.bfloat16)
+    for _ in range(3):
+        acc = acc + torch.tensor(1.0, dtype=torch.bfloat16)
+    assert float(acc) == 256.0
 
 
 # --------------------------------------------------------------------------------------- Trainer on the tiny pi0.5 model
