@@ -124,6 +124,16 @@ typedef struct kai0_gemm_desc {
      * Against gate GEMM + up GEMM with act 2: one launch, no read-back of g in the epilogue, and in inference no g / u writes. */
     const void* B2;
     void* pre_out2;
+    /* split_k > 1 only: the norm that consumes C, fused into the reduction launch (B = 1 inference, where a launch is worth
+     * 4-5 us).  norm_kind 1: RMSNorm norm_out = bf16((x * rstd) * (1 + w)), w f32 [N], rstd = rsqrt(mean(x^2) + eps)
+     * (GemmaRMSNorm without cond, modeling_gemma.py:49-104); 2: LayerNorm norm_out = bf16((x - mean) * rstd * w + b), w / b bf16
+     * [N] (nn.LayerNorm in modeling_siglip.py's encoder layers); x = the row of C as stored in bf16, statistics in f32;
+     * norm_out [M][N] bf16, contiguous.  N % 8 == 0, N <= 2048, one batch entry, bf16 C, act 0, no gate / segments. */
+    void* norm_out;
+    const void* norm_w;
+    const void* norm_b;
+    float norm_eps;
+    int32_t norm_kind;
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);

@@ -77,6 +77,12 @@ struct GemmArgs {
     // (2 x output columns).
     const bf16_t* B2;
     bf16_t* pre_out2;
+    // split-K only: the consumer's norm fused into the reduction launch (kai0hip.h norm_kind)
+    bf16_t* norm_out;
+    const void* norm_w;
+    const bf16_t* norm_b;
+    float norm_eps;
+    int norm_kind;
 };
 
 // LDS-DMA through a raw buffer descriptor: 16 B per lane from base + voff (bytes) to lds_dst + lane*16.  An offset at
@@ -1080,6 +1086,93 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
+// split-K reduction + the norm that reads its output (B = 1 inference: SigLIP out_proj -> layer_norm2, fc2 -> the next layer's
+// layer_norm1, Gemma down_proj -> the next layer's input RMSNorm): one block per output row (N <= 2048: one 8-column group per
+// thread), partials summed and the epilogue run exactly as in splitk_reduce_kernel (x stored), then the row statistics over the
+// bf16 values just stored and the normalised row.  KIND 1: y = bf16((x * rstd) * (1 + w)), w f32 (GemmaRMSNorm, modeling_gemma.py:
+// 49-104 without cond); KIND 2: y = bf16((x - mean) * rstd * w + b) (nn.LayerNorm, modeling_siglip.py).  Saves the norm's launch and
+// its read of x: at B = 1 a launch is worth 4-5 us and there are ~70 of these per action chunk.
+template <int KIND>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const GemmArgs p) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int n8 = p.N >> 3;
+    const bool live = (int)threadIdx.x < n8;
+    const int col = min((int)threadIdx.x, n8 - 1) * 8;  // idle threads repeat the last group's loads and store nothing
+    // every load of the thread is requested up front: norm weights, residual, partials
+    float wv[8], bv[8];
+    if constexpr (KIND == 1) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.norm_w) + col);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.norm_w) + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wv[e] = w0[e]; wv[4 + e] = w1[e]; bv[e] = bv[4 + e] = 0.f; }
+    } else {
+        const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.norm_w) + col);
+        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(p.norm_b + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wv[e] = bf2f(w8[e]); bv[e] = bf2f(b8[e]); }
+    }
+    bf16x8 rpre = {};
+    const bool has_res = p.residual != nullptr;
+    if (has_res) rpre = *reinterpret_cast<const bf16x8*>(p.residual + p.cmap(row) * p.ldr + col);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.split_k <= 8) {
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+            const float* wp = p.ws + ((int64_t)min(sp, p.split_k - 1) * p.M + row) * p.N + col;
+            a[sp] = *reinterpret_cast<const f32x4*>(wp);
+            b[sp] = *reinterpret_cast<const f32x4*>(wp + 4);
+        }
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+            const float m = sp < p.split_k ? 1.0f : 0.0f;
+            acc[0] += m * a[sp][0]; acc[1] += m * a[sp][1]; acc[2] += m * a[sp][2]; acc[3] += m * a[sp][3];
+            acc[4] += m * b[sp][0]; acc[5] += m * b[sp][1]; acc[6] += m * b[sp][2]; acc[7] += m * b[sp][3];
+        }
+    } else {
+        for (int sp = 0; sp < p.split_k; ++sp) {
+            const float* wp = p.ws + ((int64_t)sp * p.M + row) * p.N + col;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wp), b = *reinterpret_cast<const f32x4*>(wp + 4);
+            acc[0] += a[0]; acc[1] += a[1]; acc[2] += a[2]; acc[3] += a[3];
+            acc[4] += b[0]; acc[5] += b[1]; acc[6] += b[2]; acc[7] += b[3];
+        }
+    }
+    if (live) epilogue8(p, acc, row, col, 0, 0, 0, p.C, false, has_res ? &rpre : nullptr);  // stores x; acc = its f32 pre-image
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = live ? rbf(acc[e]) : 0.f;
+    float y[8];
+    if constexpr (KIND == 1) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+        const float rstd = rsqrtf(block_sum<4>(ss, red) / (float)p.N + p.norm_eps);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (x[e] * rstd) * (1.0f + wv[e]);
+    } else {
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += x[e];
+        const float mean = block_sum<4>(sm, red) / (float)p.N;
+        float vs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = x[e] - mean;
+            vs += live ? d * d : 0.f;
+        }
+        const float rstd = rsqrtf(block_sum<4>(vs, red) / (float)p.N + p.norm_eps);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (x[e] - mean) * rstd * wv[e] + bv[e];
+    }
+    if (live) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(y[e]);
+        *reinterpret_cast<bf16x8*>(p.norm_out + (int64_t)row * p.N + col) = o;
+    }
+}
+
 template <int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     constexpr int TBM = WM * MT * 16, TBN = WN * NT * 16;
@@ -1149,6 +1242,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
                                  (d->N % 32) == 0 && d->b_rpb == 0 && ((uintptr_t)d->B2 % 16) == 0),
                  "kai0_gemm_bf16: act=6 (GeGLU pair) needs B2 = up weight, K-contiguous operands, N %% 32 == 0, one batch entry, a "
                  "plain bf16 output");
+    KAI0_REQUIRE(d->norm_kind == 0 ||
+                     ((d->norm_kind == 1 || d->norm_kind == 2) && d->split_k > 1 && d->norm_out && d->norm_w && (d->norm_kind == 1 || d->norm_b) &&
+                      d->batch <= 1 && !d->out_f32 && d->nseg == 0 && (d->N % 8) == 0 && d->N <= 2048 && d->act == 0 && !d->gate &&
+                      !d->rowvec && ((uintptr_t)d->norm_out % 16) == 0 && ((uintptr_t)d->norm_w % 16) == 0),
+                 "kai0_gemm_bf16: a fused norm (norm_kind=%d) needs split_k > 1, norm_out / norm_w (/ norm_b), one batch entry, a plain "
+                 "bf16 output with N %% 8 == 0, N <= 2048, no activation / gate", d->norm_kind);
     KAI0_REQUIRE(d->act != 5 || (d->aux1 && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
                  "kai0_gemm_bf16: act=5 (fused GELU backward) needs aux1 = pre-activation, plain bf16 output");
     KAI0_REQUIRE(d->act != 4 || (d->aux1 && d->rowvec && !d->out_f32 && !d->accumulate && d->nseg == 0 && (d->N % 8) == 0),
@@ -1184,6 +1283,11 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.M = d->M; p.N = d->act == 6 ? 2 * d->N : d->N; p.K = d->K;  // act 6: logical width = gate | up interleaved
     p.B2 = (const bf16_t*)d->B2;
     p.pre_out2 = (bf16_t*)d->pre_out2;
+    p.norm_out = (bf16_t*)d->norm_out;
+    p.norm_w = d->norm_w;
+    p.norm_b = (const bf16_t*)d->norm_b;
+    p.norm_eps = d->norm_eps;
+    p.norm_kind = d->norm_kind;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
     p.sA1 = d->sA1; p.sA2 = d->sA2; p.sB1 = d->sB1; p.sB2 = d->sB2; p.sC1 = d->sC1; p.sC2 = d->sC2;
@@ -1256,6 +1360,11 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     if (rc) return rc;
     rc = kai0_check_launch("kai0_gemm_bf16");
     if (rc || split == 1) return rc;
+    if (d->norm_kind != 0) {
+        if (d->norm_kind == 1) hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(d->M), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(splitk_reduce_norm_kernel<2>, dim3(d->M), dim3(256), 0, s, p);
+        return kai0_check_launch("kai0_gemm_bf16(split-K reduce + norm)");
+    }
     const int64_t items = (int64_t)d->M * (d->N / 8);
     int rb = (int)((items + 255) / 256);
     if (rb > 2048) rb = 2048;

@@ -87,6 +87,8 @@ class InferenceEngine:
         self._build_stacked()
         self._times_dev = {}
         self.glue = os.environ.get("KAI0_INFER_GLUE", "1") != "0"
+        # the norm behind a split-K Linear of the SigLIP / prefix passes inside that Linear's reduction launch
+        self.fuse_norm = os.environ.get("KAI0_INFER_FUSE_NORM", "1") != "0"
         self._mods_cache = {}
         self.cache_mods = os.environ.get("KAI0_INFER_CACHE_MODS", "1") != "0"
         self._graph = None
@@ -136,18 +138,29 @@ class InferenceEngine:
         self.lm_wqkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
                         for l in lm.layers]  # fmt: skip
 
-    def _lin(self, x, w, *, bias=None, residual=None, act=0, split=None, aux1=None):
+    def _lin(self, x, w, *, bias=None, residual=None, act=0, split=None, aux1=None, norm=None):
         """flat Linear for the prefix / SigLIP passes: launches matter more than occupancy here, so the contraction is
-        only split when there are fewer than ~100 output tiles."""
+        only split when there are fewer than ~100 output tiles.
+        norm = (kind, weight, bias | None, eps): the norm that reads this Linear's output — returns (out, norm(out)); when the
+        contraction is split, the norm runs inside the split-K reduction launch (kai0hip.h norm_kind), otherwise as its own launch."""
         M, K = x.shape
         N = w.shape[0]
         if split is None:
             tiles = ((M + 127) // 128) * ((N + 127) // 128)
             split = 1 if tiles >= 100 else pick_split_k(M, N, K)
         out = torch.empty((M, N), dtype=BF16, device=self.dev)
+        fused = None
+        if norm is not None and self.fuse_norm and split > 1 and N <= 2048 and N % 8 == 0 and act == 0:
+            kind, nw, nb, neps = norm
+            fused = (kind, torch.empty((M, N), dtype=BF16, device=self.dev), nw, nb, neps)
         gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=residual, ldr=N, act=act, aux1=aux1,
-             split_k=split)
-        return out
+             split_k=split, norm=fused)
+        if norm is None:
+            return out
+        if fused is not None:
+            return out, fused[1]
+        kind, nw, nb, neps = norm
+        return out, (ops.rmsnorm(out, nw, neps) if kind == 1 else ops.layernorm(out, nw, nb, neps))
 
     def _siglip(self, image):
         """SigLIP tower for inference (modeling_siglip.py:271-281,325-460,756-778): stacked q|k|v projection, attention
@@ -163,18 +176,23 @@ class InferenceEngine:
         x = ops.patch_embed(image.contiguous(), emb.patch_embedding.weight, emb.patch_embedding.bias,
                             emb.position_embedding.weight, sc.patch_size)  # fmt: skip
         scale = HD**-0.5
-        for l, layer in enumerate(vt.encoder.layers):
-            h = ops.layernorm(x, layer.layer_norm1.weight, layer.layer_norm1.bias, layer.layer_norm1.eps)
+        layers = list(vt.encoder.layers)
+        h = ops.layernorm(x, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, layers[0].layer_norm1.eps)
+        for l, layer in enumerate(layers):
             qkv = self._lin(h, self.sg_wqkv[l], bias=self.sg_bqkv[l])
             a = torch.empty((n * S, E), dtype=BF16, device=self.dev)
             ops.attn_fwd(qkv, qkv[:, E:], qkv[:, 2 * E:], a, None, rows=S, Sk=S, HD=HD, H=1, batch=n * NH, batch_inner=NH,
                          ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, sQ=(S * 3 * E, HD), sK=(S * 3 * E, HD), sV=(S * 3 * E, HD),
                          sO=(S * E, HD), scale=scale)  # fmt: skip
-            x = self._lin(a, layer.self_attn.out_proj.weight, bias=layer.self_attn.out_proj.bias, residual=x)
-            h = ops.layernorm(x, layer.layer_norm2.weight, layer.layer_norm2.bias, layer.layer_norm2.eps)
+            # each norm is handed to the Linear that produces its input (out_proj -> layer_norm2, fc2 -> the next layer's layer_norm1 /
+            # the post-layernorm): split-K Linears run it inside their reduction launch
+            ln2 = layer.layer_norm2
+            x, h = self._lin(a, layer.self_attn.out_proj.weight, bias=layer.self_attn.out_proj.bias, residual=x,
+                             norm=(2, ln2.weight, ln2.bias, ln2.eps))  # fmt: skip
             f = self._lin(h, layer.mlp.fc1.weight, bias=layer.mlp.fc1.bias, act=1)
-            x = self._lin(f, layer.mlp.fc2.weight, bias=layer.mlp.fc2.bias, residual=x)
-        x = ops.layernorm(x, vt.post_layernorm.weight, vt.post_layernorm.bias, vt.post_layernorm.eps)
+            nxt = layers[l + 1].layer_norm1 if l + 1 < len(layers) else vt.post_layernorm
+            x, h = self._lin(f, layer.mlp.fc2.weight, bias=layer.mlp.fc2.bias, residual=x, norm=(2, nxt.weight, nxt.bias, nxt.eps))
+        x = h  # = post_layernorm(x)
         proj = pe.paligemma.model.multi_modal_projector.linear
         return self._lin(x, proj.weight, bias=proj.bias).view(n, S, -1)
 
@@ -291,8 +309,9 @@ class InferenceEngine:
         xp = prefix.reshape(B * P, self.Dp)
         NQ = H * HD
         M = B * P
-        for l, layer in enumerate(lm.layers):
-            hp = ops.rmsnorm(xp, layer.input_layernorm.weight, layer.input_layernorm.eps)
+        lm_layers = list(lm.layers)
+        hp = ops.rmsnorm(xp, lm_layers[0].input_layernorm.weight, lm_layers[0].input_layernorm.eps)
+        for l, layer in enumerate(lm_layers):
             at = layer.self_attn
             if l == self.L - 1:
                 # nothing consumes the last prefix layer's attention / MLP output: only its K and V rows are needed
@@ -317,8 +336,9 @@ class InferenceEngine:
             else:
                 g = self._lin(hp, wg)
                 hmid = self._lin(hp, wu, act=2, aux1=g)  # GeGLU in the epilogue
-            xp = self._lin(hmid, layer.mlp.down_proj.weight, residual=xp,
-                           split=_PREFIX_SPLITS[2] or pick_split_k(M, self.Dp, hmid.shape[1]))
+            nxt = lm_layers[l + 1].input_layernorm  # (the loop leaves at the last layer: there is always a next one here)
+            xp, hp = self._lin(hmid, layer.mlp.down_proj.weight, residual=xp, norm=(1, nxt.weight, None, nxt.eps),
+                               split=_PREFIX_SPLITS[2] or pick_split_k(M, self.Dp, hmid.shape[1]))
 
     def _modulations(self, times: list[float]):
         """time embedding -> time MLP -> adaRMS `dense` for every layer and step at once (rows = step*B + b): one f32 GEMM over

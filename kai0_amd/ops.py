@@ -55,7 +55,7 @@ def gemm(
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
     aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None, rowvec=None, rv=(0, 0, 1),
-    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None,
+    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None, norm=None,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -116,6 +116,14 @@ def gemm(
     if split_k > 1:
         ws = _workspace(batch * split_k * M * N * 4, A.device)
         d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel()
+    if norm is not None:  # (kind, norm_out, weight, bias | None, eps): the consumer's norm, fused into the split-K reduction
+        kind, nout, nw, nb, neps = norm
+        _chk(nout, BF16, "gemm: norm_out")
+        _chk(nw, F32 if kind == 1 else BF16, "gemm: norm weight")
+        d.norm_kind, d.norm_out, d.norm_w, d.norm_eps = int(kind), nout.data_ptr(), nw.data_ptr(), float(neps)
+        if nb is not None:
+            _chk(nb, BF16, "gemm: norm bias")
+            d.norm_b = nb.data_ptr()
     _lib.call("kai0_gemm_bf16", C.byref(d), _stream())
     return out
 

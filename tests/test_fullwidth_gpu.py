@@ -284,6 +284,14 @@ def test_fullwidth_chunk_switches_agree(fw, monkeypatch):
             assert torch.equal(m.sample_actions(d, gobs, noise=noise, num_steps=10), ref)
         finally:
             ops.set_geglu_pair(old)
+        # the norms behind the split-K Linears as launches of their own (kai0hip.h norm_kind off): same arithmetic, another
+        # summation order of the row statistics (block-wide instead of wave-wide)
+        assert m._engine.fuse_norm
+        monkeypatch.setenv("KAI0_INFER_FUSE_NORM", "0")
+        m.invalidate_inference_engine()
+        sep = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        print(f"chunk with separate norm launches vs fused: rel-L2 {rel(sep, ref):.3e}")
+        assert not m._engine.fuse_norm and rel(sep, ref) < 2e-3, rel(sep, ref)
     finally:
         m.invalidate_inference_engine()
         m.train()

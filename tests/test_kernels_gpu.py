@@ -698,6 +698,34 @@ def test_adamw_and_clip(ops):
         assert torch.equal(p.detach(), m.to(p.dtype))
 
 
+@pytest.mark.parametrize("kind,M,N,K,split", [(2, 768, 1152, 4304, 4), (2, 768, 1152, 1152, 3), (1, 968, 2048, 16384, 6), (1, 50, 64, 512, 2),
+                                             (2, 37, 1152, 4304, 12)])
+def test_splitk_gemm_with_the_consumer_norm_in_its_reduction(ops, kind, M, N, K, split):
+    """kai0_gemm_bf16 norm_kind: x = Linear(a) + bias + residual exactly as without it (bit-identical), and norm(x) against the
+    separate norm kernels (same arithmetic; the row statistics are summed block-wide instead of wave-wide) and an fp32 reference."""
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    nw = rnd(N, dtype=F32 if kind == 1 else BF16, seed=5, scale=0.3)
+    nb = None if kind == 1 else rnd(N, seed=6, scale=0.3)
+    eps = 1e-6
+    want = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, w, want, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=res, ldr=N, split_k=split)
+    got, normed = torch.empty_like(want), torch.zeros_like(want)
+    ops.gemm(a, w, got, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=res, ldr=N, split_k=split, norm=(kind, normed, nw, nb, eps))
+    assert torch.equal(got, want)
+    sep = ops.rmsnorm(want, nw, eps) if kind == 1 else ops.layernorm(want, nw, nb, eps)
+    x = want.float()
+    if kind == 1:
+        ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * (1 + nw)
+    else:
+        ref = torch.nn.functional.layer_norm(x, (N,), nw.float(), nb.float(), eps)
+    assert_close_bf16(normed, ref, what="fused norm vs fp32", tol=1e-2)
+    mism = (normed != sep).float().mean().item()
+    assert mism < 2e-3 and rel_err(normed, sep) < 1e-3, (mism, rel_err(normed, sep))
+    with pytest.raises(Exception, match="split_k > 1"):
+        ops.gemm(a, w, got, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, split_k=1, norm=(kind, normed, nw, nb, eps))
+
+
 @pytest.mark.parametrize("dtype", [BF16, F32])
 @pytest.mark.parametrize("chunks,n", [(1, 4096), (4, 1024 * 37), (8, 8 * 250_001)])
 def test_sum_chunks_is_an_f32_sum_with_one_rounding(ops, dtype, chunks, n):
