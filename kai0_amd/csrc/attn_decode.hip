@@ -33,6 +33,7 @@ struct DecArgs {
     int rows, H, Sk, q0, k_rows;
     int64_t q_bs, k_bs, k_ld, vt_bs, vt_ld, qc_ld, kc_ld;
     float scale;
+    int range_major;  // 1: blockIdx.x = key range / head-dim slice, blockIdx.y = query tile (see kai0_attn_decode); 0: the former order
 };
 
 constexpr int DEC_HD = 256;
@@ -62,14 +63,14 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const DecArgs p, bf16_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, r0 = blockIdx.x * 16;
+    const int b = blockIdx.z, r0 = (p.range_major ? blockIdx.y : blockIdx.x) * 16, kr = p.range_major ? blockIdx.x : blockIdx.y;
     const int rq = r0 + i;
     const bool qok = rq < p.rows;
     char* my = dec_smem + wave * DEC_STAGE;
     // this wave's 64 keys (two 32-key groups) as 32 contiguous 1-KiB reads: instruction q covers key rows 2q, 2q + 1.  Rows 16-31
     // of each 32-row group are stored with their 16-B column index xor 4: the fragment reads below touch rows {0-3, 8-11, 16-19,
     // 24-27} of a group per 16 lanes, and with a 528-B row stride rows r and r + 16 would share their banks.
-    const int key0 = (blockIdx.y * 4 + wave) * NG * 32;
+    const int key0 = (kr * 4 + wave) * NG * 32;
     const bf16_t* Kb = p.K + (int64_t)b * p.k_bs;
     {
         const int sub = lane >> 5, c16 = lane & 31;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void dec_pv_kernel(const DecArgs p, const bf16
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, r0 = blockIdx.x * 16, h0 = blockIdx.y * (16 * HT);
+    const int b = blockIdx.z, r0 = (p.range_major ? blockIdx.y : blockIdx.x) * 16, h0 = (p.range_major ? blockIdx.x : blockIdx.y) * (16 * HT);
     const int ngroups = (p.Sk + 31) >> 5;
     // wave w owns the 256 keys [256 w, 256 w + 256) = key groups 8 w .. 8 w + 7; lane (q, g) keys 8g..8g+7 of each group
     // logits of row r0 + i
@@ -262,15 +263,22 @@ KAI0_API int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void
     // few query tiles (B = 1: 25): eight key ranges / eight head-dim slices per tile instead of four, so that 200 blocks share
     // the staging of the caches instead of 100
     static const int fine = [] { const char* e = getenv("KAI0_DEC_FINE"); return e ? atoi(e) : 1; }();
+    // Range-major grids: a workgroup's XCD is its linear id % 8 (tools/probes/xcc_map.hip), so with the key range / head-dim slice in
+    // blockIdx.x (8 or 4 of them) every block that stages the same rows of the K / V cache runs on the same XCD and the rows cross
+    // the fabric once per launch instead of once per XCD (query-tile-major: 5.9 / 10.9 MB fetched per launch for 0.7 / 1.3 MB of
+    // operands, profiles/r03_infer_chunk_pmc.txt).  KAI0_DEC_RANGE_MAJOR=0: the former order.
+    static const int rmaj = [] { const char* e = getenv("KAI0_DEC_RANGE_MAJOR"); return e ? atoi(e) : 1; }();
+    p.range_major = rmaj;
+    auto grid = [&](int ranges) { return rmaj ? dim3(ranges, qt, batch) : dim3(qt, ranges, batch); };
     if (fine && (int64_t)qt * batch <= 32) {
-        hipLaunchKernelGGL(dec_logits_kernel<1>, dim3(qt, 2 * DEC_KSPLIT, batch), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
+        hipLaunchKernelGGL(dec_logits_kernel<1>, grid(2 * DEC_KSPLIT), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
                            (bf16_t*)workspace, l_bs);
-        hipLaunchKernelGGL(dec_pv_kernel<2>, dim3(qt, 2 * DEC_HSPLIT, batch), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
+        hipLaunchKernelGGL(dec_pv_kernel<2>, grid(2 * DEC_HSPLIT), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
                            (const bf16_t*)workspace, l_bs);
     } else {
-        hipLaunchKernelGGL(dec_logits_kernel<2>, dim3(qt, DEC_KSPLIT, batch), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
+        hipLaunchKernelGGL(dec_logits_kernel<2>, grid(DEC_KSPLIT), dim3(256), DEC_LOGITS_LDS, (hipStream_t)stream, p,
                            (bf16_t*)workspace, l_bs);
-        hipLaunchKernelGGL(dec_pv_kernel<4>, dim3(qt, DEC_HSPLIT, batch), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
+        hipLaunchKernelGGL(dec_pv_kernel<4>, grid(DEC_HSPLIT), dim3(256), DEC_PV_LDS, (hipStream_t)stream, p,
                            (const bf16_t*)workspace, l_bs);
     }
     return kai0_check_launch("kai0_attn_decode");
