@@ -31,8 +31,10 @@ from .ops import BF16, F32, gemm, pick_split_k, round_up
 
 logger = logging.getLogger("kai0_amd")
 # split-K of the prefix pass's q|k|v, o_proj and down_proj GEMMs ("q,o,d"; 0 = ops.pick_split_k).  Swept on MI355X at B = 1
-# (tools/prefix_splits.sh): 1,1,6 -> prefix pass 6.52 ms; the automatic rule 6.80; everything else within 0.1-0.25 ms
-_PREFIX_SPLITS = [int(x) for x in os.environ.get("KAI0_PREFIX_SPLITS", "1,1,6").split(",")]
+# (tools/prefix_splits.sh): 1,1,6 -> prefix pass 6.52 ms; the automatic rule 6.80; everything else within 0.1-0.25 ms.  Round 3: with
+# the post-attention RMSNorm inside o_proj's reduction launch (kai0hip.h norm_kind) a split o_proj costs no extra launch: 1,2,6 ->
+# 5.56 against 5.68 ms for 1,1,6 (3 and 4: 5.58 / 5.59)
+_PREFIX_SPLITS = [int(x) for x in os.environ.get("KAI0_PREFIX_SPLITS", "1,2,6").split(",")]
 
 
 def NQ_ok(nq: int) -> bool:
@@ -276,16 +278,25 @@ class InferenceEngine:
         gemm(x, lin.weight, dst, M=M, N=width, K=K, lda=K, ldb=K, ldc=width, c_map=(rows_pb, self.S_ld, row0),
              split_k=pick_split_k(M, width, K))
 
-    def _oproj(self, lin, rows_pb: int, row0: int, residual, gate=None):
-        """y = att_buf[b, row0 + r] @ Wo^T (+gate) + residual, reading the padded buffer through the A row remap."""
+    def _oproj(self, lin, rows_pb: int, row0: int, residual, gate=None, norm=None):
+        """y = att_buf[b, row0 + r] @ Wo^T (+gate) + residual, reading the padded buffer through the A row remap.
+        norm = (kind, weight, bias | None, eps): returns (y, norm(y)), the norm inside the split-K reduction when there is one."""
         B, H, HD = self.B, self.H, self.HD
         M = B * rows_pb
         N = lin.weight.shape[0]
         out = torch.empty((M, N), dtype=BF16, device=self.dev)
+        split = (_PREFIX_SPLITS[1] if M > 128 else 0) or pick_split_k(M, N, H * HD)
+        fused = None
+        if norm is not None and self.fuse_norm and split > 1 and N <= 2048 and N % 8 == 0 and gate is None:
+            fused = (norm[0], torch.empty((M, N), dtype=BF16, device=self.dev), norm[1], norm[2], norm[3])
         gemm(self.att_buf, lin.weight, out, M=M, N=N, K=H * HD, lda=H * HD, ldb=H * HD, ldc=N,
              a_map=(rows_pb, self.S_ld, row0), residual=residual, ldr=N, gate=gate, gate_rpb=rows_pb, gate_ld=N,
-             split_k=(_PREFIX_SPLITS[1] if M > 128 else 0) or pick_split_k(M, N, H * HD))  # fmt: skip
-        return out
+             split_k=split, norm=fused)  # fmt: skip
+        if norm is None:
+            return out
+        if fused is not None:
+            return out, fused[1]
+        return out, (ops.rmsnorm(out, norm[1], norm[3]) if norm[0] == 1 else ops.layernorm(out, norm[1], norm[2], norm[3]))
 
     # ------------------------------------------------------------------------------------------------ passes
     def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks):
@@ -326,8 +337,8 @@ class InferenceEngine:
                  split_k=_PREFIX_SPLITS[0] or 1)  # fmt: skip
             ops.rope2_(self.q_buf, H, self.k_cache[l], 1, self.pos_prefix, inv_freq, B, P, S_ld, 0, HD)  # q and k: one launch
             self._attend(l, 0, P, P, qcode, kcode)
-            xp = self._oproj(at.o_proj, P, 0, residual=xp)
-            hp = ops.rmsnorm(xp, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
+            pan = layer.post_attention_layernorm
+            xp, hp = self._oproj(at.o_proj, P, 0, residual=xp, norm=(1, pan.weight, None, pan.eps))
             wg, wu = layer.mlp.gate_proj.weight, layer.mlp.up_proj.weight
             if ops._GEGLU_PAIR and wg.shape[0] % 32 == 0:
                 # gate | up as one GEMM over both weights, GeGLU in registers: only h is written
