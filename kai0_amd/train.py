@@ -213,6 +213,11 @@ def build_model(config, device):
         model = model_cfg._model_class()(model_cfg)
     if hasattr(model, "gradient_checkpointing_enable") and os.environ.get("KAI0_REMAT", "0") == "1":
         model.gradient_checkpointing_enable()  # the reference force-enables it; 288 GB of HBM make it optional here
+    if hasattr(model, "trim_prompt_padding") and os.environ.get("KAI0_TRIM_PROMPT", "1") != "0":
+        # the prompt slots no sample of the batch uses are not computed (kai0's task prompts fill 10-40 of the 200 slots; padded slots are
+        # invisible keys and unread rows: loss and gradients unchanged beyond summation order, tests/test_model_gpu.py).  bench.py
+        # measures with it off — every one of the 200 slots computed, as the reference does — and reports the trimmed rate beside it.
+        model.trim_prompt_padding = True
     if config.pytorch_weight_path is not None:
         load_model_safetensors(model, os.path.join(config.pytorch_weight_path, "model.safetensors"),
                                strict=not config.advantage_estimator)  # fmt: skip
