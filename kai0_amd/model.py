@@ -489,11 +489,28 @@ class PI0Pytorch(nn.Module):
         # parity tests switch it off and inject noise/time.
         self.train_augmentation = True
         self.trim_prompt_padding = False  # training forward: drop the prompt slots no sample of the batch uses (_trim_prompt)
+        # sample_actions: the same for the request's prompt (the tokenizer pads every prompt to max_token_len; a task prompt fills
+        # 10-40 of pi0.5's 200 slots).  Off here — the model computes what the reference computes; policy.create_trained_policy turns
+        # it on for the serve path.  Engines are kept per (batch, prompt slots, cameras), a few at a time (_ENGINE_SLOTS).
+        self.trim_prompt_padding_infer = False
         self._engine = None
 
     # ---- reference API ------------------------------------------------------------------------------------
     # The inference engine holds stacked weight copies and a captured hipGraph: anything that can change or move the
     # parameters drops it (it is rebuilt on the next sample_actions call).
+    _ENGINE_SLOTS = 4
+
+    @property
+    def _engine(self):
+        """the engine of the last sample_actions call (None: nothing built, or dropped)"""
+        return self.__dict__.get("_engine_cur")
+
+    @_engine.setter
+    def _engine(self, eng):
+        if eng is None:  # dropping the engine drops every cached one: they all hold copies of the same weights
+            self.__dict__["_engine_lru"] = {}
+        self.__dict__["_engine_cur"] = eng
+
     def invalidate_inference_engine(self):
         self._engine = None
 
@@ -570,8 +587,8 @@ class PI0Pytorch(nn.Module):
 
     @staticmethod
     def _trim_prompt(lang_tokens, lang_masks):
-        """Opt-in (`model.trim_prompt_padding = True`; training forward only): cut the prompt to the longest valid prompt of the
-        batch, rounded up to 8 tokens.  The tokenizer pads at the end (tokenizer.py:22-47), padded tokens are invisible as keys
+        """Opt-in (`model.trim_prompt_padding = True` for the training forward, `trim_prompt_padding_infer` for sample_actions): cut
+        the prompt to the longest valid prompt of the batch, rounded up to 8 tokens.  The tokenizer pads at the end (tokenizer.py:22-47), padded tokens are invisible as keys
         (`make_att_2d_masks`) and their rows are read by nobody, so the loss and the gradients do not change beyond summation
         order — but every prefix-row GEMM shrinks with the rows (200 slots for 64-128 valid tokens in the bench's synthetic
         prompts: 968 -> 896 prefix rows).  Costs one scalar device-to-host read per step (the host waits for the stream once)."""
@@ -666,9 +683,20 @@ class PI0Pytorch(nn.Module):
         wait = getattr(self.paligemma_with_expert.unit_hooks, "wait_params", None)
         if wait is not None:  # a sharded trainer owns the parameters: its in-flight all-gathers must have landed
             wait()
-        if self._engine is None or not self._engine.compatible(bsize, lang_tokens.shape[1], len(images)):
-            self._engine = InferenceEngine(self, bsize, lang_tokens.shape[1], len(images))
-        return self._engine.sample_actions(images, img_masks, lang_tokens, lang_masks, noise.to(F32), num_steps)
+        if self.trim_prompt_padding_infer:
+            lang_tokens, lang_masks = self._trim_prompt(lang_tokens, lang_masks)
+        key = (bsize, lang_tokens.shape[1], len(images))
+        eng = self._engine
+        if eng is None or not eng.compatible(*key):
+            lru = self.__dict__.setdefault("_engine_lru", {})
+            eng = lru.pop(key, None)
+            if eng is None or not eng.compatible(*key):
+                eng = InferenceEngine(self, *key)
+            lru[key] = eng  # (re-)inserted last: most recently used
+            while len(lru) > self._ENGINE_SLOTS:
+                lru.pop(next(iter(lru)))
+            self.__dict__["_engine_cur"] = eng
+        return eng.sample_actions(images, img_masks, lang_tokens, lang_masks, noise.to(F32), num_steps)
 
 
 class AdvantageEstimator(PI0Pytorch):

@@ -11,6 +11,7 @@ static buffers and hipGraph are not re-entrant (SURVEY.md §8b "Threading")."""
 from __future__ import annotations
 
 import abc
+import os
 import time
 from collections.abc import Mapping, Sequence
 from typing import Any
@@ -121,6 +122,10 @@ def create_trained_policy(train_config, checkpoint_dir, *, repack_transforms: _t
                                 "checkpoint has to go through kai0_amd.convert first")  # fmt: skip
     model = train_config.model.load_pytorch(train_config, weight_path)
     model.paligemma_with_expert.to_bfloat16_for_selected_params("bfloat16")
+    if hasattr(model, "trim_prompt_padding_infer") and os.environ.get("KAI0_TRIM_PROMPT", "1") != "0":
+        # serve path: the prompt slots the request's prompt does not fill are not computed (model.py _trim_prompt; a task prompt
+        # fills 10-40 of pi0.5's 200 slots: 18 % fewer prefix rows).  Same action chunk up to summation order.
+        model.trim_prompt_padding_infer = True
     data_config = train_config.data.create(train_config.assets_dirs, train_config.model)
     if norm_stats is None:
         if data_config.asset_id is None:

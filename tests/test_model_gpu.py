@@ -487,6 +487,49 @@ def test_trimmed_prompt_padding_gives_the_same_loss_and_gradients(pair):
     m.zero_grad(set_to_none=True)
 
 
+def test_trimmed_prompt_gives_the_same_action_chunk_and_engines_are_kept_per_shape(pair):
+    """`model.trim_prompt_padding_infer = True` (the serve path's default, policy.create_trained_policy): sample_actions cuts the
+    prompt to the request's valid tokens (rounded up to 8) — padded slots are invisible keys and unread rows, so the chunk may only
+    move by summation order.  Engines are cached per (batch, prompt slots, cameras): alternating prompt lengths does not rebuild."""
+    import copy
+
+    m, dev = pair["model"], pair["dev"]
+    obs = pair["gobs"]
+    mask = obs.tokenized_prompt_mask
+    assert int(mask.sum(1).max()) + 8 <= mask.shape[1], "the fixture needs padded prompt slots for this test"
+    noise = pair["noise"].to(dev)
+    m.eval()
+    try:
+        m.invalidate_inference_engine()
+        full = m.sample_actions(dev, obs, noise=noise, num_steps=10)
+        e_full = m._engine
+        assert e_full.T == mask.shape[1]
+        m.trim_prompt_padding_infer = True
+        trimmed = m.sample_actions(dev, obs, noise=noise, num_steps=10)
+        e_trim = m._engine
+        assert e_trim is not e_full and e_trim.T < e_full.T and e_trim.T % 8 == 0 and e_trim.T >= int(mask.sum(1).max())
+        r = rel(trimmed, full)
+        print(f"trimmed ({e_trim.T} of {e_full.T} prompt slots) vs full action chunk: rel-L2 {r:.3e}")
+        assert r < 2e-3
+        # a shorter prompt -> another engine; back to the first length -> the cached engine and its captured graph
+        short = mask.clone()
+        short[:, 8:] = False
+        obs2 = copy.copy(obs)
+        obs2.tokenized_prompt_mask = short
+        m.sample_actions(dev, obs2, noise=noise, num_steps=10)
+        assert m._engine.T == 8 and m._engine is not e_trim
+        again = m.sample_actions(dev, obs, noise=noise, num_steps=10)
+        assert m._engine is e_trim and torch.equal(again, trimmed)
+        m.trim_prompt_padding_infer = False
+        assert torch.equal(m.sample_actions(dev, obs, noise=noise, num_steps=10), full) and m._engine is e_full
+        m.invalidate_inference_engine()
+        assert m._engine is None and not m.__dict__["_engine_lru"]
+    finally:
+        m.trim_prompt_padding_infer = False
+        m.invalidate_inference_engine()
+        m.train()
+
+
 @pytest.mark.timeout(600)
 def test_train_loop_debug_pi05_resume_is_exact(tmp_path):
     """`train_loop(get_config("debug_pi05"))` over the HIP model (scripts/train_pytorch.py:309-633): 6 steps in one
