@@ -9,7 +9,7 @@ training step in the exact launch configuration the real model uses:
   * the transposed-operand weight-gradient GEMM (ring schedule) at 16384 x 2048 x 30976, on sampled output rows.
 
 Tolerances (bf16 path vs fp32 oracle / fp32 torch reference of the same op): loss tensor rel-L2 <= 1e-2; 10-step action chunk
-rel-L2 <= 5e-3 and max|d| <= 2e-2 vs the bf16-choreography oracle, rel-L2 <= 1e-2 vs the fp32 oracle; parameter gradients
+rel-L2 <= 3e-3 and max|d| <= 2e-2 vs the bf16-choreography oracle, rel-L2 <= 1e-2 vs the fp32 oracle; parameter gradients
 rel-L2 <= 3e-2 vs fp32 autograd (about twice the worst measured on MI355X, see gpurun_out/grad_table_fullwidth.txt)."""
 
 import copy
@@ -134,7 +134,7 @@ def test_fullwidth_action_chunk_matches_oracle(fw, batch):
         mx = float((out.cpu() - ref).abs().max())
         print(f"full-width chunk B={batch}: rel-L2 {r:.3e} (max|d| {mx:.3e}) vs bf16 oracle, {r32:.3e} vs fp32 oracle")
         assert out.shape == (batch, 50, 32) and out.dtype == F32
-        assert r <= 5e-3 and mx <= 2e-2 and r32 <= 1e-2
+        assert r <= 3e-3 and mx <= 2e-2 and r32 <= 1e-2
         assert torch.equal(out, m.sample_actions(d, gobs, noise=noise.to(d), num_steps=10))  # replay is deterministic
     finally:
         m.train()
