@@ -1,7 +1,7 @@
 #!/bin/bash
 # LDS / wait counters of the two big GEMM schedules (NT quadrant, TN ring) on single shapes
 set -u
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r3q; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/gemm_lds_pmc; rm -rf $O; mkdir -p $O
 i=0
 for SHAPE in "TN 16384 2048 30976" "NT 30976 2048 16384" "NT 30976 16384 2048"; do
   i=$((i+1))
