@@ -39,6 +39,7 @@ cases = [
     ("down  NT 30976x2048x16384", 30976, 2048, 16384, 0),
     ("o/q   NT 30976x2048x2048 ", 30976, 2048, 2048, 0),
     ("fc1   NT 24576x4304x1152 ", 24576, 4304, 1152, 0),
+    ("fc1 + bias + GELU (act 1) ", 24576, 4304, 1152, 1),
     ("fc2   NT 24576x1152x4304 ", 24576, 1152, 4304, 0),
     ("B=1 gate NT 968x16384x2048", 968, 16384, 2048, 0),
     ("square 8192              ", 8192, 8192, 8192, 0),
@@ -81,6 +82,8 @@ for name, M, N, K, act in cases:
         extra = dict(act=act, aux1=g, pre_out=pre, split_k=1)
         if act == 3:
             extra["aux2"] = u
+        if act == 1:  # SigLIP fc1 forward: bias, pre-activation kept for the backward, tanh-GELU
+            extra = dict(act=1, pre_out=pre, bias=torch.randn(N, device=dev).to(BF16), split_k=1)
 
     def run(c):
         set_cfg(c)
