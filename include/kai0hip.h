@@ -96,7 +96,11 @@ typedef struct kai0_gemm_desc {
     /* split-K (few output tiles: long-contraction wgrads, skinny M = 50 inference GEMMs): split_k > 1 cuts K into
      * split_k chunks, each block writes an f32 partial tile into `workspace` (>= batch*split_k*M*N*4 bytes) and a
      * second kernel sums them and applies the same fused epilogue once.  Needs N % 8 == 0. */
-    int32_t split_k, _pad1;
+    int32_t split_k;
+    /* != 0: C (bf16) is stored with the non-temporal hint — for outputs nothing reads again soon (weight gradients: written during
+     * the backward, read by the optimizer at the end of the step), so that they do not displace the operands of the following
+     * launches from L2 / Infinity Cache.  Same bits in memory; a hint only. */
+    int32_t c_nontemporal;
     void* workspace;
     int64_t workspace_bytes;
     const void* aux1; /* act 2/3: bf16 [rows][ldc], addressed like C */

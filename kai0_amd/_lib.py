@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("out_f32", C.c_int32),
         ("pre_out", c_p), ("gate", c_p), ("gate_rpb", C.c_int32), ("accumulate", C.c_int32),
         ("gate_ld", c_i64), ("residual", c_p), ("ldr", c_i64), ("sR1", c_i64), ("sR2", c_i64),
-        ("split_k", C.c_int32), ("_pad1", C.c_int32), ("workspace", c_p), ("workspace_bytes", c_i64),
+        ("split_k", C.c_int32), ("c_nontemporal", C.c_int32), ("workspace", c_p), ("workspace_bytes", c_i64),
         ("aux1", c_p), ("aux2", c_p),
         ("nseg", C.c_int32), ("_pad2", C.c_int32), ("seg", GemmSeg * 3),
         ("rowvec", c_p), ("rv_s1", c_i64), ("rv_s2", c_i64), ("rv_ld", c_i64),

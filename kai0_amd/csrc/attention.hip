@@ -56,6 +56,7 @@ struct AttnArgs {
     int64_t qcode_ld, kcode_ld;
     float scale;
     int kc_lds_keys;  // > 0: the key codes of the launch's key range are staged in LDS once per block (round_up(Sk, 64) entries)
+    int nt_p;    // P stored with the non-temporal hint (KAI0_ATTN_NT_P, default 1)
     int ablate;  // diagnostics only (KAI0_ATTN_ABLATE bit mask, timing runs): 1 no P store, 2 no pass 1, 4 no P V MFMAs,
                  // 8 no DMA inside the tile loops, 16 no logits MFMAs in pass 2 — results are wrong with any bit set
 };
@@ -261,7 +262,10 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
                 const int r = row0 + lr, key = kt * 64 + c8;
                 const u32x4 pv = *reinterpret_cast<const u32x4*>(pbuf + lr * 128 + c8 * 2);
                 const uint32_t off = (r < p.rows && key < p.ldp) ? (uint32_t)(((int64_t)r * p.ldp + key) * 2) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(pv, p_rsrc, (int)off, 0, 0);
+                // P is read again only by the backward, a whole forward later: non-temporal (aux bit 1 = nt), so that the 0.5 GB
+                // of a launch do not displace what the next kernels are about to read from L2 / Infinity Cache
+                if (p.nt_p) __builtin_amdgcn_raw_buffer_store_b128(pv, p_rsrc, (int)off, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(pv, p_rsrc, (int)off, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -488,6 +492,8 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     p.scale = d->scale;
     static const int ablate = [] { const char* e = getenv("KAI0_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
+    static const int nt_p = [] { const char* e = getenv("KAI0_ATTN_NT_P"); return e ? atoi(e) : 1; }();
+    p.nt_p = nt_p;
     static const int kc_lds = [] { const char* e = getenv("KAI0_ATTN_KC_LDS"); return e ? atoi(e) : 1; }();
     const int kc_keys = ((d->Sk + 63) / 64) * 64;
     p.kc_lds_keys = (kc_lds && kc_keys <= KC_LDS_MAX) ? kc_keys : 0;  // longer key ranges read their codes from global

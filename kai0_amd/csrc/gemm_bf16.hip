@@ -63,6 +63,8 @@ struct GemmArgs {
     int64_t ldr, sR1, sR2;
     int tiles_m, tiles_n;
     int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
+    int nt_c;    // C stored non-temporally (kai0hip.h c_nontemporal: weight gradients, read again only by the optimizer)
+    int nt_pre;  // pre-activation outputs (pre_out / pre_out2 of act 1 and 6: read again only by the backward) stored non-temporally
     const float* rowvec;   // act 4: per-row f32 vector D (softmax backward), index z1*rv_s1 + z2*rv_s2 + row*rv_ld
     int64_t rv_s1, rv_s2, rv_ld;
     int nseg;              // > 0: bf16 output columns are routed to up to 3 destinations (fused q|k|v projection)
@@ -97,6 +99,11 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t vof
 // Swizzle key of a contraction-strided (MC) tile row r: key(r) = (r & 3) | (((r >> 3) & 1) << 2).
 // It spreads the 8 k-rows that a 32-lane half of ds_read_b64_tr_b16 touches ({0..3, 8..11} + 4h) over the 8
 // distinct 32-B segments of the 256-B bank row.  Both the DMA source address and the read address apply it.
+
+__device__ __forceinline__ void store_pre8(bf16_t* dst, bf16x8 v, int nt) {
+    if (nt) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
+    else *reinterpret_cast<bf16x8*>(dst) = v;
+}
 
 // The fused epilogue on 8 consecutive columns [ccol, ccol+8) of output row `row` (v = f32 accumulators), shared by the
 // GEMM kernel and the split-K reduction.  Order and rounding points: see kai0hip.h.
@@ -141,7 +148,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
             bf16x8 pv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
-            *reinterpret_cast<bf16x8*>(p.pre_out + cz + orow * p.ldc + ccol) = pv;
+            store_pre8(p.pre_out + cz + orow * p.ldc + ccol, pv, p.nt_pre);
         }
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
@@ -227,7 +234,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, float (&v)[8], int 
         bf16x8 ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x8*>(cp) = ov;
+        store_pre8(cp, ov, p.nt_c);
     }
 }
 
@@ -843,8 +850,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 }
                 const int64_t o = cz + p.cmap(row) * p.ldc + ocol;
                 *reinterpret_cast<bf16x8*>(cb + o) = hb;
-                if (p.pre_out != nullptr) *reinterpret_cast<bf16x8*>(p.pre_out + o) = gb;
-                if (p.pre_out2 != nullptr) *reinterpret_cast<bf16x8*>(p.pre_out2 + o) = ub;
+                if (p.pre_out != nullptr) store_pre8(p.pre_out + o, gb, p.nt_pre);
+                if (p.pre_out2 != nullptr) store_pre8(p.pre_out2 + o, ub, p.nt_pre);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                         bf16x8 pv;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
-                        *reinterpret_cast<bf16x8*>(p.pre_out + o) = pv;
+                        store_pre8(p.pre_out + o, pv, p.nt_pre);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
@@ -1304,7 +1311,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.accumulate = d->accumulate;
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
     static const int ablate = [] { const char* e = getenv("KAI0_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    p.ablate = ablate;  // diagnostics: 1 = no DMA in the K loop (compute + LDS-read ceiling)
+    p.ablate = ablate;
+    // non-temporal stores for what only the backward / the optimizer reads again (KAI0_GEMM_NT=0: plain stores, for A/B runs)
+    // (bit 0: pre-activation outputs, bit 1: C when the caller sets c_nontemporal)
+    static const int nt_on = [] { const char* e = getenv("KAI0_GEMM_NT"); return e ? atoi(e) : 3; }();
+    p.nt_pre = nt_on & 1;
+    p.nt_c = (nt_on & 2) && d->c_nontemporal;  // diagnostics: 1 = no DMA in the K loop (compute + LDS-read ceiling)
     p.rowvec = d->rowvec; p.rv_s1 = d->rv_s1; p.rv_s2 = d->rv_s2; p.rv_ld = d->rv_ld;
     p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {

@@ -55,7 +55,7 @@ def gemm(
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
     aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None, rowvec=None, rv=(0, 0, 1),
-    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None, norm=None,
+    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None, norm=None, nt_out: bool = False,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -104,6 +104,7 @@ def gemm(
         d.ldr = ldr
         d.sR1, d.sR2 = sR
     d.accumulate = int(accumulate)
+    d.c_nontemporal = int(nt_out)  # weight gradients: stored past the caches (kai0hip.h)
     if rowvec is not None:  # act 4: D index = z1*rv[0] + z2*rv[1] + row*rv[2]
         if rowvec.dtype != F32:
             raise TypeError("gemm: rowvec must be f32")
@@ -460,7 +461,7 @@ class LinearFn(torch.autograd.Function):
             # directly, so no gradient copy is needed afterwards (sharded.py)
             dw = _grad_dst(w, BF16)
             # dw[N,K] = dy[M,N]^T @ x[M,K]  (both stored [contraction][cols])
-            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M))
+            gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M), nt_out=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _grad_dst(ctx.bias, ctx.bias_dtype)
             scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=x.device)
@@ -617,7 +618,7 @@ class LinearMultiFn(torch.autograd.Function):
                 first = False
             if ctx.needs_input_grad[2 + i]:
                 dw = _grad_dst(w, BF16)
-                gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M))
+                gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M), nt_out=True)
                 dws[i] = _grad_ret(w, dw)
             if b is not None and ctx.needs_input_grad[2 + n + i]:
                 db = _grad_dst(b, b.dtype)
@@ -892,7 +893,7 @@ class GegluMlpFn(torch.autograd.Function):
 
         def wgrad(dy, inp, w, n, k):
             dw = _grad_dst(w, BF16)
-            gemm(dy, inp, dw, M=n, N=k, K=M, a_kc=False, b_kc=False, lda=n, ldb=k, ldc=k, split_k=pick_split_k_wgrad(n, k, M))
+            gemm(dy, inp, dw, M=n, N=k, K=M, a_kc=False, b_kc=False, lda=n, ldb=k, ldc=k, split_k=pick_split_k_wgrad(n, k, M), nt_out=True)
             return dw
 
         dwd = wgrad(dout, h, wd, D, F) if ctx.needs_input_grad[3] else None
@@ -963,7 +964,7 @@ class GeluMlpFn(torch.autograd.Function):
         dw2 = db2 = dw1 = db1 = dx = None
         if ctx.needs_input_grad[3]:
             dw2 = _grad_dst(w2, BF16)
-            gemm(dout, h, dw2, M=Do, N=F, K=M, a_kc=False, b_kc=False, lda=Do, ldb=ldh, ldc=F, split_k=pick_split_k_wgrad(Do, F, M))
+            gemm(dout, h, dw2, M=Do, N=F, K=M, a_kc=False, b_kc=False, lda=Do, ldb=ldh, ldc=F, split_k=pick_split_k_wgrad(Do, F, M), nt_out=True)
             dw2 = _grad_ret(w2, dw2)
         if b2 is not None and ctx.needs_input_grad[4]:
             db2 = colsum(dout, Do, Do, b2)
@@ -977,7 +978,7 @@ class GeluMlpFn(torch.autograd.Function):
             gemm(dout, w2, dpre, M=M, N=F, K=Do, a_kc=True, b_kc=False, lda=Do, ldb=F, ldc=ldh, act=5, aux1=pre)
         if ctx.needs_input_grad[1]:
             dw1 = _grad_dst(w1, BF16)
-            gemm(dpre, x, dw1, M=F, N=D, K=M, a_kc=False, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k_wgrad(F, D, M))
+            gemm(dpre, x, dw1, M=F, N=D, K=M, a_kc=False, b_kc=False, lda=ldh, ldb=D, ldc=D, split_k=pick_split_k_wgrad(F, D, M), nt_out=True)
             dw1 = _grad_ret(w1, dw1)
         if b1 is not None and ctx.needs_input_grad[2]:
             db1 = colsum(dpre, F, ldh, b1)
