@@ -1,7 +1,7 @@
 """Model-level parity: HIP pi0.5 (through the C-ABI) vs the CPU oracle on identical weights / inputs / noise.
 
 Tolerances (stated here, defended in DESIGN.md §parity): the reference pins no model numerics, so the bar is
-ours: vs the bf16-choreography oracle rel-L2 <= 1e-2 on the loss tensor and <= 5e-3 / max|d| <= 2e-2 on the
+ours: vs the bf16-choreography oracle rel-L2 <= 1e-2 on the loss tensor and <= 3e-3 / max|d| <= 2e-2 on the
 10-step action chunk; vs the fp32 oracle rel-L2 <= 1e-2 on the chunk.  Masks / position ids are bit-exact
 (tests/test_host_cpu.py)."""
 
@@ -98,13 +98,13 @@ def test_sample_actions_matches_oracle_and_golden(pair):
     r = rel(out, ref)
     mx = float((out.cpu() - ref).abs().max())
     print(f"action chunk vs bf16 oracle: rel-L2 {r:.3e}, max|d| {mx:.3e}")
-    assert r < 5e-3 and mx < 2e-2
+    assert r < 3e-3 and mx < 2e-2
     o32 = copy.deepcopy(oracle)
     o32.paligemma_with_expert.to_bfloat16_for_selected_params("float32")
     ref32 = o32.sample_actions(pair["obs"], pair["noise"], num_steps=10)
     assert rel(out, ref32) < 1e-2 and float((out.cpu() - ref32).abs().max()) < 2e-2
     gold = load_file(os.path.join(HERE, "golden", "tiny_pi05.safetensors"))
-    assert rel(out, gold["actions"]) < 5e-3
+    assert rel(out, gold["actions"]) < 3e-3
     # graph replay is deterministic and equals the eager HIP launches
     out2 = m.sample_actions(dev, pair["gobs"], noise=pair["noise"].to(dev), num_steps=10)
     assert torch.equal(out, out2)
@@ -127,7 +127,7 @@ def test_against_reference_executed_end_to_end(pair):
     loss = m(pair["gobs"], pair["actions"].to(dev), noise=pair["noise"].to(dev), time=pair["time"].to(dev))
     assert rel(loss, E["loss"]) <= 1e-2
     out = m.sample_actions(dev, pair["gobs"], noise=pair["noise"].to(dev))
-    assert rel(out, E["actions"]) <= 5e-3 and float((out.float().cpu() - E["actions"]).abs().max()) <= 2e-2
+    assert rel(out, E["actions"]) <= 3e-3 and float((out.float().cpu() - E["actions"]).abs().max()) <= 2e-2
 
 
 def test_gradients_against_reference_executed_backward(pair):
