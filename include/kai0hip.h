@@ -231,6 +231,22 @@ int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void* O, cons
 int kai0_attn_bwd_dq(const void* dO, const void* O, const void* P, const void* K, const void* V, void* dS, void* dQ, int batch,
                      int rows, int Sk, int HD, int64_t ldo, int64_t ldk, int64_t ldv, int64_t ldp, int64_t sO, int64_t sK,
                      int64_t sV, int64_t sP, float scale, kai0_stream_t stream);
+/* The same with the probabilities RECOMPUTED instead of read (round 4: the one-pass forward stores lse, not P — kai0_attn_desc.lse):
+ *   S = bf16(bf16(Q K^T) * scale) masked with the codes exactly as kai0_attn_fwd does;  P = bf16(exp(S - lse[row]))
+ * P is an OUTPUT here ([batch][rows][ldp], written once, columns >= Sk zero) for the dV = P^T dO GEMM that follows; everything
+ * else as kai0_attn_bwd_dq.  Q has the layout of dO / O (rows of HD elements, row stride ldo, batch stride sO); folded row r is
+ * head r % H of query position r / H (qcode index).  Sk <= 2048.  Replaces the backward of eager_attention_forward
+ * (modeling_gemma.py:228-253) without a stored S x S tensor between forward and backward. */
+typedef struct kai0_attn_bwd_desc {
+    const void* dO; const void* O; const void* Q; const void* K; const void* V;
+    const float* lse; const int32_t* qcode; const int32_t* kcode;
+    void* P; void* dS; void* dQ;
+    int32_t batch, rows, Sk, HD, H, _pad0;
+    int64_t ldo, ldk, ldv, ldp, sO, sK, sV, sP, s_lse, qcode_ld, kcode_ld;
+    float scale; int32_t _pad1;
+} kai0_attn_bwd_desc;
+int kai0_attn_bwd_dq2(const kai0_attn_bwd_desc* d, kai0_stream_t stream);
+int kai0_attn_bwd_desc_size(void); /* sizeof(kai0_attn_bwd_desc): bindings check their mirror against it at load */
 /* bytes of the bf16 logits scratch kai0_attn_decode needs */
 int64_t kai0_attn_decode_workspace_bytes(int batch, int rows);
 /* batched strided transpose: dst[z][c][r] = src[z][r][c], r < R, c < C (all extents / strides multiples of 8) */
@@ -334,6 +350,11 @@ int kai0_softmax_mask_fwd(const void* scores, void* probs, const int32_t* qcode,
 int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void* dO, const void* O, const void* P,
                          void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD, int64_t ldp, int64_t ld_grad,
                          float scale, kai0_stream_t stream);
+/* The same without stored probabilities (round 4): P = bf16(exp(bf16(bf16(q k^T) * scale) - lse[row])) is recomputed inside the
+ * block from the q / k tiles that are in LDS anyway; lse: f32 [n_img * NH][S] from kai0_attn_fwd (kai0_attn_desc.lse). */
+int kai0_siglip_attn_bwd2(const void* q, const void* k, const void* v, const void* dO, const void* O, const float* lse,
+                          void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD, int64_t ld_grad, float scale,
+                          kai0_stream_t stream);
 /* out[r] = sum_d a[r][d] * b[r][d] in f32 (rows of D contiguous bf16 elements, D % 8 == 0): the softmax-backward row term */
 int kai0_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int D, kai0_stream_t stream);
 /* dscores = bf16( (probs * (dprobs - sum_j dprobs*probs)) * scale ).  dprobs is bf16 or (dprobs_f32) f32:
@@ -354,9 +375,16 @@ typedef struct kai0_attn_desc {
     int64_t ldq, ldk, ldv, ldo, ldp;
     int64_t sQ1, sQ2, sK1, sK2, sV1, sV2, sO1, sO2, sP;
     int64_t qcode_ld, kcode_ld;
-    float scale; int32_t _pad1;
+    float scale;
+    int32_t online;   /* 0: one pass with an online softmax when P == NULL (training: the backward recomputes P from lse), the exact
+                       * two-pass form when P is asked for; 1: one pass required (P must be NULL); 2: never */
+    float* lse;       /* optional [batch][s_lse] f32: log-sum-exp of every query row's (scaled, masked) logits, +inf for a row
+                       * that sees no key.  exp(logit - lse) is the row's softmax: what kai0_attn_bwd_dq2 /
+                       * kai0_siglip_attn_bwd2 recompute instead of reading P */
+    int64_t s_lse;    /* batch stride of lse (>= rows) */
 } kai0_attn_desc;
 int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream);
+int kai0_attn_desc_size(void); /* sizeof(kai0_attn_desc) */
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces.

@@ -58,6 +58,19 @@ class AttnDesc(C.Structure):
         ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64), ("ldp", c_i64),
         ("sQ1", c_i64), ("sQ2", c_i64), ("sK1", c_i64), ("sK2", c_i64), ("sV1", c_i64), ("sV2", c_i64),
         ("sO1", c_i64), ("sO2", c_i64), ("sP", c_i64), ("qcode_ld", c_i64), ("kcode_ld", c_i64),
+        ("scale", c_f), ("online", C.c_int32), ("lse", c_p), ("s_lse", c_i64),
+    ]  # fmt: skip
+
+
+class AttnBwdDesc(C.Structure):
+    """Mirror of `kai0_attn_bwd_desc` (include/kai0hip.h)."""
+
+    _fields_ = [
+        ("dO", c_p), ("O", c_p), ("Q", c_p), ("K", c_p), ("V", c_p), ("lse", c_p), ("qcode", c_p), ("kcode", c_p),
+        ("P", c_p), ("dS", c_p), ("dQ", c_p),
+        ("batch", C.c_int32), ("rows", C.c_int32), ("Sk", C.c_int32), ("HD", C.c_int32), ("H", C.c_int32), ("_pad0", C.c_int32),
+        ("ldo", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldp", c_i64), ("sO", c_i64), ("sK", c_i64), ("sV", c_i64), ("sP", c_i64),
+        ("s_lse", c_i64), ("qcode_ld", c_i64), ("kcode_ld", c_i64),
         ("scale", c_f), ("_pad1", C.c_int32),
     ]  # fmt: skip
 
@@ -92,6 +105,10 @@ _PROTOS: dict[str, list] = {
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "kai0_attn_fwd": [C.POINTER(AttnDesc), c_p],
+    "kai0_attn_desc_size": [],
+    "kai0_attn_bwd_dq2": [C.POINTER(AttnBwdDesc), c_p],
+    "kai0_attn_bwd_desc_size": [],
+    "kai0_siglip_attn_bwd2": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_f, c_p],
     "kai0_gemm_skinny_bf16": [C.POINTER(SkinnyDesc), c_p],
     "kai0_skinny_desc_size": [],
     "kai0_attn_decode": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i64, c_i64,
@@ -184,6 +201,9 @@ def load() -> C.CDLL:
         raise Kai0HipError(
             f"kai0_gemm_desc layout mismatch: C {lib.kai0_gemm_desc_size()} B vs ctypes {C.sizeof(GemmDesc)} B"
         )
+    for fn, mirror in (("kai0_attn_desc_size", AttnDesc), ("kai0_attn_bwd_desc_size", AttnBwdDesc)):
+        if getattr(lib, fn)() != C.sizeof(mirror):
+            raise Kai0HipError(f"{fn[:-5]} layout mismatch: C {getattr(lib, fn)()} B vs ctypes {C.sizeof(mirror)} B")
     lib.kai0_attn_decode_workspace_bytes.restype = c_i64
     lib.kai0_attn_decode_workspace_bytes.argtypes = [c_i, c_i]
     lib.kai0_skinny_workspace_bytes.restype = c_i64

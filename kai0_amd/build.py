@@ -15,16 +15,34 @@ OUT = HERE / "lib" / "libkai0hip.so"
 # (-ffp-contract=fast) even contracts ACROSS an explicit bf16 round trip (it narrows fpext*fpext products to
 # bf16 ops and then forms a bf16 fma), which silently removes the bf16 rounding points this library emulates.
 def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
-    srcs = [HERE / "csrc" / s for s in SRC]
-    deps = srcs + [HERE / "csrc" / "common.h", HERE.parent / "include" / "kai0hip.h"]
-    if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return OUT
-    OUT.parent.mkdir(parents=True, exist_ok=True)
+    """Compile every csrc/*.hip to an object (in parallel, only the stale ones) and link libkai0hip.so."""
     import os
+    from concurrent.futures import ThreadPoolExecutor
 
+    srcs = [HERE / "csrc" / s for s in SRC]
+    common = [HERE / "csrc" / "common.h", HERE.parent / "include" / "kai0hip.h", pathlib.Path(__file__)]
     extra = os.environ.get("KAI0_HIPCC_FLAGS", "").split()  # e.g. -DKAI0_SK2_TRACE (tools/probes/sk2_phases.py)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", *extra,
-           *map(str, srcs), "-o", str(OUT)]  # fmt: skip
+    objdir = OUT.parent / ("obj" + ("_" + "_".join(f.strip("-") for f in extra) if extra else ""))
+    objdir.mkdir(parents=True, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", *extra]
+    newest_common = max(d.stat().st_mtime for d in common)
+
+    def compile_one(src: pathlib.Path) -> tuple[pathlib.Path, bool]:
+        obj = objdir / (src.stem + ".o")
+        if not force and obj.exists() and obj.stat().st_mtime >= max(src.stat().st_mtime, newest_common):
+            return obj, False
+        cmd = ["hipcc", *flags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        results = list(pool.map(compile_one, srcs))
+    objs = [o for o, _ in results]
+    if not force and OUT.exists() and not any(c for _, c in results) and all(OUT.stat().st_mtime >= o.stat().st_mtime for o in objs):
+        return OUT
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *map(str, objs), "-o", str(OUT)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -4,10 +4,15 @@
 // points: logits = bf16(bf16(Q K^T) * scale), softmax in f32, P = bf16(softmax), O = bf16(P V).
 //
 // gfx950 design:
-//   * "two-pass" instead of online softmax: pass 1 sweeps the key tiles computing the row max / row sum (Q K^T only),
-//     pass 2 recomputes the logits, writes the FINAL normalised P (which the GEMM-based backward consumes) and
-//     accumulates O with that bf16 P.  No accumulator rescaling, no S x S logits round trip through HBM, and bitwise
-//     the reference's rounding order.  Q K^T is cheap here (1/3 of the MFMAs) and K stays in L2.
+//   * training (round 4): ONE pass with an online softmax (OP = -1): per key tile the logits are computed once, the running row
+//     max m and row sum l are updated, O is rescaled by exp(m_old - m_new) when a row's max moved, P~ = bf16(exp(s - m)) goes
+//     straight into P V; at the end O /= l and lse = m + log(l) is written per row.  NO probabilities leave the chip: the
+//     backward recomputes them from Q, K and lse (attn_bwd.hip, attn_bwd_siglip.hip).  The logits keep the reference's rounding
+//     (bf16(bf16(Q K^T) * scale)); the point where P is rounded to bf16 moves from "after the normalisation" to "before" —
+//     inside the stated floating-point tolerance, not bit-identical to eager_attention_forward.
+//   * the former "two-pass" form (OP = 0: pass 1 row max / row sum, pass 2 recomputes the logits, writes the FINAL normalised P
+//     and accumulates O with that bf16 P — bitwise the reference's rounding order) is kept for callers that ask for P and as the
+//     A/B alternative (KAI0_ATTN_ONLINE=0).
 //   * transposed orientation: S^T = K Q^T and O^T = V^T P^T.  The C-layout of S^T (lane = query column, registers =
 //     4 consecutive keys) IS the B-operand layout of the second MFMA, so P never leaves registers; softmax statistics
 //     are per lane (no cross-lane traffic in the key loop); V^T comes from a row-major V tile through
@@ -56,6 +61,8 @@ struct AttnArgs {
     int64_t qcode_ld, kcode_ld;
     float scale;
     int kc_lds_keys;  // > 0: the key codes of the launch's key range are staged in LDS once per block (round_up(Sk, 64) entries)
+    float* lse;          // optional [batch][s_lse] f32: log-sum-exp of every query row's logits (+inf for rows that see no key)
+    int64_t s_lse;
     int nt_p;    // P stored with the non-temporal hint (KAI0_ATTN_NT_P, default 1)
     int ablate;  // diagnostics only (KAI0_ATTN_ABLATE bit mask, timing runs): 1 no P store, 2 no pass 1, 4 no P V MFMAs,
                  // 8 no DMA inside the tile loops, 16 no logits MFMAs in pass 2 — results are wrong with any bit set
@@ -66,14 +73,14 @@ struct AttnArgs {
 // wave's MFMAs overlap the other's softmax VALU work and LDS reads — the block, its K / V tiles and LDS footprint are the same.
 // OP > 0: single pass for Sk <= 64 * OP keys — all OP key tiles (K and V) are staged into LDS at once, the logits of the whole
 // row stay in registers (OP x 4 x QT accumulators), so Q K^T is computed once and there is no per-tile barrier; OP = 0: the
-// general two-pass form (pass 1: row max / sum, pass 2: recompute the logits, P, P V).
+// general two-pass form (pass 1: row max / sum, pass 2: recompute the logits, P, P V); OP = -1: one pass, online softmax (no P).
 // RB = query rows per block (128; 64: four waves, ONE staging buffer, 80 KiB of LDS -> two independent blocks per CU that cover each
 // other's DMA waits and softmax chains instead of eight lockstep waves).
 template <int NKS, int VC, int QT, int OP = 0, int RB = 128>
 __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int WAVES = RB / (16 * QT);
     constexpr int NST = RB == 64 ? 1 : 2;  // staging buffers of the two-pass form
-    static_assert(RB == 128 || (RB == 64 && OP == 0 && QT == 1), "64-row blocks: two passes, one 16-row tile per wave");
+    static_assert(RB == 128 || (RB == 64 && OP <= 0 && QT == 1), "64-row blocks: two passes / online, one 16-row tile per wave");
     constexpr int OMT = VC / 16;
     constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
     constexpr int K_BYTES = NKS * 8192;             // NKS x [64 keys][64 d] bf16
@@ -350,10 +357,81 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
             l += __shfl_xor(l, 32, 64);
             m_run[nt] = m;
             inv_l[nt] = l > 0.f ? 1.0f / l : 0.f;
+            const int r = row0 + nt * 16 + l15;
+            if (p.lse != nullptr && g == 0 && r < p.rows) p.lse[(int64_t)z * p.s_lse + r] = l > 0.f ? m + __logf(l) : INFINITY;
         }
 #pragma unroll
         for (int t = 0; t < OP; ++t)
             if (t < ntiles) emit_tile(t, smem + t * STAGE + K_BYTES, sall[t], m_run, inv_l);
+    } else if constexpr (OP < 0) {
+        // ============================ one pass, online softmax: no probabilities leave the chip =======================
+        // Per lane: query column l15 of tile nt, keys 16 mt + 4 g + r of every key tile.  The row max is made uniform over the
+        // four lane groups of a column every tile (two shuffles), so all of them scale O and l by the same factors and the
+        // partial row sums can simply be added at the end.
+        float m_run[QT], l_run[QT];
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) { m_run[nt] = -INFINITY; l_run[nt] = 0.f; }
+        stage(0, 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int buf = NST == 2 ? (kt & 1) : 0;
+            if (NST == 2 && kt + 1 < ntiles) stage(kt + 1, buf ^ 1, true);
+            const char* tk = smem + buf * STAGE;
+            int kc[4][4];
+            load_kcodes(kt, kc);
+            f32x4 s[4][QT];
+            logits(tk, s);
+            finish_logits(kt, s, kc);
+            bf16x4 pb[4][QT];
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[mt][nt][r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mn = fmaxf(m_run[nt], tmax);
+                const bool live = mn > -INFINITY;                                  // the row has seen a visible key
+                const float alpha = live ? __expf(m_run[nt] - mn) : 1.0f;          // m_run = -inf: 0 (O and l are still 0)
+                float lsum = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = live ? __expf(s[mt][nt][r] - mn) : 0.f;    // masked: exp(-inf) = 0
+                        lsum += e;
+                        pb[mt][nt][r] = f2bf(e);
+                    }
+                l_run[nt] = l_run[nt] * alpha + lsum;
+                m_run[nt] = mn;
+                // O of this column is rescaled BEFORE the tile's P V is added (the whole pending state is at the old max)
+                if (__any(alpha != 1.0f)) {
+#pragma unroll
+                    for (int mt = 0; mt < OMT; ++mt) o[mt][nt] *= alpha;
+                }
+            }
+            pv_tile(tk + K_BYTES, pb);
+            if (NST == 1) {
+                lds_barrier();
+                if (kt + 1 < ntiles) stage(kt + 1, 0, true);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) {
+            float l = l_run[nt];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < OMT; ++mt) o[mt][nt] *= inv;
+            const int r = row0 + nt * 16 + l15;
+            if (p.lse != nullptr && g == 0 && r < p.rows) p.lse[(int64_t)z * p.s_lse + r] = l > 0.f ? m_run[nt] + __logf(l) : INFINITY;
+        }
     } else {
     // ================================ pass 1: row max and row sum =====================================================
     float m_run[QT], l_run[QT];
@@ -409,6 +487,8 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         }
         m_run[nt] = m;
         inv_l[nt] = l > 0.f ? 1.0f / l : 0.f;
+        const int r = row0 + nt * 16 + l15;
+        if (p.lse != nullptr && g == 0 && r < p.rows) p.lse[(int64_t)z * p.s_lse + r] = l > 0.f ? m + __logf(l) : INFINITY;
     }
 
     // ================================ pass 2: P and O = P V ===========================================================
@@ -465,6 +545,8 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
 
 }  // namespace
 
+KAI0_API int kai0_attn_desc_size(void) { return (int)sizeof(kai0_attn_desc); }
+
 KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d != nullptr && d->Q && d->K && d->V && d->O, "kai0_attn_fwd: null operand");
     KAI0_REQUIRE(d->HD % 8 == 0 && d->HD > 0 && d->HD <= 256, "kai0_attn_fwd: HD=%d unsupported", d->HD);
@@ -490,6 +572,8 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     p.sO1 = d->sO1; p.sO2 = d->sO2; p.sP = d->sP;
     p.qcode_ld = d->qcode_ld; p.kcode_ld = d->kcode_ld;
     p.scale = d->scale;
+    p.lse = d->lse; p.s_lse = d->s_lse;
+    KAI0_REQUIRE(d->lse == nullptr || d->s_lse >= d->rows, "kai0_attn_fwd: s_lse=%lld < rows", (long long)d->s_lse);
     static const int ablate = [] { const char* e = getenv("KAI0_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
     static const int nt_p = [] { const char* e = getenv("KAI0_ATTN_NT_P"); return e ? atoi(e) : 1; }();
@@ -505,6 +589,7 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
 #define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP, RB)                                                                          \
     do {                                                                                                          \
         constexpr int LDS = (OP > 0 ? OP : (RB == 64 ? 1 : 2)) * (NKS * 8192 + 64 * VC * 2) + (RB / 32) * 4096 + KC_LDS_MAX * 4; \
+        static_assert(LDS <= 160 * 1024, "attention LDS budget");                                                    \
         static bool attr_set = false;                                                                             \
         auto kern = attn_fwd_kernel<NKS, VC, QT, OP, RB>;                                                             \
         if (!attr_set) {                                                                                          \
@@ -520,14 +605,25 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     // (Measured and rejected, round 3: the two wave groups of pass 2 one barrier slot apart — group 0 in [logits, softmax, P store]
     // while group 1 is in [P V] — 1.095 against 0.965 ms: the phases are latency-bound, two lockstep waves per SIMD already cover
     // each other, and a slot lasts as long as its longer phase.)
+    // one pass with an online softmax whenever the caller does not ask for P (d->online: 0 = that rule, 1 = must, 2 = never;
+    // KAI0_ATTN_ONLINE=0 turns the rule off for A/B runs).  For <= 256 keys at HD <= 128 (SigLIP) the resident single-pass form is
+    // exact AND one pass, so it stays.
+    static const int online_env = [] { const char* e = getenv("KAI0_ATTN_ONLINE"); return e ? atoi(e) : 1; }();
+    KAI0_REQUIRE(d->online != 1 || d->P == nullptr, "kai0_attn_fwd: the one-pass form does not produce P");
+    const bool online = d->P == nullptr && d->online != 2 && (d->online == 1 || online_env);
+    static const int op_grid = [] { const char* e = getenv("KAI0_ATTN_ONEPASS_GRID"); return e ? atoi(e) : 512; }();
     if (d->HD <= 128) {
-        if (qt == 2) KAI0_ATTN_LAUNCH(2, 128, 2, 0, 128);
+        if (qt == 2 && !online) KAI0_ATTN_LAUNCH(2, 128, 2, 0, 128);
+        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= op_grid) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
+        else if (online) KAI0_ATTN_LAUNCH(2, 128, 1, -1, 128);
         // 256 keys = 4 resident tiles (144 KiB, one block per CU): wins when the grid is at most a round or two of the chip
         // (B = 1 inference: 26 -> 19 us); with thousands of blocks the two-pass form's two 80-KiB blocks per CU are as fast
         else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
         else KAI0_ATTN_LAUNCH(2, 128, 1, 0, 128);
     } else {
-        if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, 128);
+        if (online && qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, -1, 128);
+        else if (online) KAI0_ATTN_LAUNCH(4, 256, 1, -1, 128);
+        else if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, 128);
         else if (small) KAI0_ATTN_LAUNCH(4, 256, 1, 0, 64);
         else KAI0_ATTN_LAUNCH(4, 256, 1, 0, 128);
     }

@@ -4,7 +4,14 @@
 //     dP   = dO V^T                 (f32, never rounded, never written)
 //     dS   = bf16((P * (dP - D)) * scale)                     (written once: dK = dS^T Q still needs it)
 //     dQ   = dS K                                              (f32 accumulate, bf16 out)
-// in ONE launch.  It replaces kai0_rowdot_bf16 + the K = 256 GEMM with the softmax-backward epilogue (all epilogue: 4 K-tiles
+// in ONE launch.  Round 4 (RC = true, kai0_attn_bwd_dq2): P is not read but RECOMPUTED per key tile — S^T = K Q^T from the K tile
+// that is in LDS anyway (the row-major image serves both the b128 row reads of this product and the transpose reads of
+// dQ^T += K^T dS^T: with the key swizzle below the 16 lanes of every ds_read_b128 group fall on 16 distinct 16-byte slots), the
+// logits rounded and masked exactly as the forward does, P = bf16(exp(s - lse[row])) with the forward's per-row log-sum-exp —
+// and WRITTEN once (bf16) next to dS for the two batched GEMMs dV = P^T dO, dK = dS^T Q that follow.  The forward therefore
+// stores no probabilities (attention.hip, OP = -1); one extra product here against one fewer pass and one fewer S x S store
+// there, and P never sits in HBM between forward and backward (9.6 GB per step at B = 32).
+// It replaces kai0_rowdot_bf16 + the K = 256 GEMM with the softmax-backward epilogue (all epilogue: 4 K-tiles
 // per 256x256 tile, 277 TFLOP/s) + the dQ GEMM that re-read dS: P is read once, dS written once, dO / V / K stay on chip.
 // P is the forward's stored bf16 probabilities — recomputing them (a "flash" backward) would cost 7 GEMM-units of MFMA work
 // instead of 4 at HD = 256 and the forward keeps P for dV = P^T dO anyway.
@@ -17,6 +24,7 @@
 // the 16-byte slice of P it needs, the 16-byte slice of dS it writes, and the B fragment of the second product.
 #include "common.h"
 #include "../../include/kai0hip.h"
+#include <limits.h>
 #include <stdlib.h>
 
 namespace {
@@ -34,12 +42,21 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr int AB_KC_MAX = 2048;  // key codes staged in LDS (RC): covers S = 1018 and the estimator's 1786
 
 struct AbArgs {
     const bf16_t* dO;
     const bf16_t* O;
-    const bf16_t* P;
+    const bf16_t* P;      // RC: not read
+    bf16_t* Pout;         // RC: the recomputed probabilities, same layout as dS
+    const bf16_t* Q;      // RC
+    const float* lse;     // RC: [batch][s_lse]
+    const int32_t* qcode; // RC, optional (with kcode): mask codes, query position of folded row r = r / H
+    const int32_t* kcode;
+    int64_t s_lse, qcode_ld, kcode_ld;
+    int H;
     const bf16_t* K;
     const bf16_t* V;
     bf16_t* dS;
@@ -51,7 +68,7 @@ struct AbArgs {
 };
 
 // NKS = 64-wide sub-tiles over the head dim (HD <= 64 * NKS)
-template <int NKS>
+template <int NKS, bool RC>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
     constexpr int KSTEPS = NKS * 2;                // 32-wide contraction steps over the head dim
     constexpr int VT_BYTES = NKS * 8192;           // V: NKS x [64 keys][64 d] bf16, 128-B rows
@@ -80,6 +97,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Pb, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t ds_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dSb, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t po_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(RC ? p.Pout + (int64_t)z * p.sP : dSb), 0, (int)OOB, 0x00020000);
+    int* kc_lds = reinterpret_cast<int*>(smem + 2 * STAGE);  // RC: key codes of the whole key range
     const int row = blockIdx.x * 128 + wave * 16 + l15;  // this lane's query row (MFMA column)
     const bool rok = row < p.rows;
     const int ntiles = (p.Sk + 63) / 64;
@@ -107,6 +127,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
             for (int e = 0; e < 8; ++e) dsum += bf2f(dof[ks][e]) * bf2f(of[ks][e]);
         dsum += __shfl_xor(dsum, 16, 64);
         dsum += __shfl_xor(dsum, 32, 64);
+    }
+
+    // ---- RC: Q fragments (B operand of S^T = K Q^T, same lane layout as dO), the row's log-sum-exp and mask code ---------
+    bf16x8 qf[RC ? KSTEPS : 1];
+    float lse_row = INFINITY;
+    int qc = INT_MAX;
+    if constexpr (RC) {
+        const bf16_t* Qb = p.Q + (int64_t)z * p.sO;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rok && d < p.HD) a = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)row * p.ldo + d);
+            qf[ks] = a;
+        }
+        if (rok) lse_row = p.lse[(int64_t)z * p.s_lse + row];
+        if (p.qcode != nullptr) qc = rok ? p.qcode[(int64_t)z * p.qcode_ld + row / p.H] : -1;
+        const int nkc = ((p.Sk + 63) / 64) * 64;
+        for (int i = tid; i < nkc; i += 512) kc_lds[i] = p.kcode == nullptr ? 0 : (i < p.Sk ? p.kcode[(int64_t)z * p.kcode_ld + i] : INT_MAX);
     }
 
     // ---- staging (attention.hip's layouts with the roles of K and V swapped) ------------------------------------------------
@@ -145,8 +184,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
     for (int dt = 0; dt < ODT; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int arow = 8 * (l15 >> 2) + (l15 & 3);  // key (within a 32-key group) fed to A-row l15 of tile 0; tile 1: + 4
 
-    u32x4 pn0 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(0, 0), 0, 0);
-    u32x4 pn1 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(0, 1), 0, 0);
+    u32x4 pn0 = {0, 0, 0, 0}, pn1 = {0, 0, 0, 0};
+    if constexpr (!RC) {
+        pn0 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(0, 0), 0, 0);
+        pn1 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(0, 1), 0, 0);
+    }
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -156,8 +198,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
         // next tile's P slices first, then its K / V tiles: the P loads are older than the DMA, so waiting for them later
         // never waits for the tiles
         if (kt + 1 < ntiles) {
-            pn0 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(kt + 1, 0), 0, 0);
-            pn1 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(kt + 1, 1), 0, 0);
+            if constexpr (!RC) {
+                pn0 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(kt + 1, 0), 0, 0);
+                pn1 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(kt + 1, 1), 0, 0);
+            }
             stage(kt + 1, buf ^ 1);
         }
         const char* tv = smem + buf * STAGE;
@@ -176,9 +220,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[ks], a1, 0, 0, 0);
             }
             // lane (row, g) holds dP for keys 64 kt + 32 hh + 8 g + e  (e < 4: a0, e >= 4: a1)
-            const u32x4 pw = pc[hh];
             bf16x8 pv;
-            __builtin_memcpy(&pv, &pw, 16);
+            if constexpr (RC) {
+                // S^T for the same (key, row) pairs: A = K rows (b128 reads of the row-major image), B = Q fragments
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                const int r0 = hh * 32 + arow, r1 = r0 + 4;
+                const int key0 = ((r0 & 3) | (((r0 >> 3) & 1) << 2)) << 1, key1 = ((r1 & 3) | (((r1 >> 3) & 1) << 2)) << 1;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int chunk = ks * 4 + g;
+                    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tk + r0 * K_ROWB + ((chunk ^ key0) << 4));
+                    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(tk + r1 * K_ROWB + ((chunk ^ key1) << 4));
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[ks], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[ks], s1, 0, 0, 0);
+                }
+                const int kbase = kt * 64 + hh * 32 + 8 * g;
+                const i32x4 c0 = *reinterpret_cast<const i32x4*>(kc_lds + kbase), c1 = *reinterpret_cast<const i32x4*>(kc_lds + kbase + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = rbf(rbf(e < 4 ? s0[e] : s1[e - 4]) * p.scale);   // the forward's rounding points
+                    const bool ok = (kbase + e < p.Sk) && ((e < 4 ? c0[e] : c1[e - 4]) <= qc);
+                    pv[e] = f2bf(ok ? __expf(sv - lse_row) : 0.f);                    // lse = +inf (row sees no key): 0
+                }
+                u32x4 pw;
+                __builtin_memcpy(&pw, &pv, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pw, po_rsrc, (int)p_off(kt, hh), 0, 0);  // always issued (OOB = dropped)
+            } else {
+                const u32x4 pw = pc[hh];
+                __builtin_memcpy(&pv, &pw, 16);
+            }
             bf16x8 ds;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ds[e] = f2bf((bf2f(pv[e]) * ((e < 4 ? a0[e] : a1[e - 4]) - dsum)) * p.scale);
@@ -200,8 +270,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
                 accq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ds, accq[dt], 0, 0, 0);
             }
         }
-        // the next tile's DMA and P loads must have landed; the two dS stores issued after them may still fly
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // the next tile's DMA and P loads must have landed; the two dS (RC: + two P) stores issued after them may still fly
+        if constexpr (RC) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         lds_barrier();
     }
     // ---- dQ: lane (row, g) holds d = 16 dt + 4 g + r ---------------------------------------------------------------------
@@ -221,10 +292,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
 
 }  // namespace
 
-KAI0_API int kai0_attn_bwd_dq(const void* dO, const void* O, const void* P, const void* K, const void* V, void* dS, void* dQ,
+static int attn_bwd_dq_launch(const void* dO, const void* O, const void* P, const void* K, const void* V, void* dS, void* dQ,
                               int batch, int rows, int Sk, int HD, int64_t ldo, int64_t ldk, int64_t ldv, int64_t ldp,
-                              int64_t sO, int64_t sK, int64_t sV, int64_t sP, float scale, kai0_stream_t stream) {
+                              int64_t sO, int64_t sK, int64_t sV, int64_t sP, float scale, kai0_stream_t stream,
+                              const void* Q, const float* lse, int64_t s_lse, const int32_t* qcode, int64_t qcode_ld,
+                              const int32_t* kcode, int64_t kcode_ld, int H, bool rc) {
     KAI0_REQUIRE(dO && O && P && K && V && dS && dQ, "kai0_attn_bwd_dq: null operand");
+    KAI0_REQUIRE(!rc || (Q && lse && s_lse >= rows && H >= 1 && ((qcode == nullptr) == (kcode == nullptr)) && Sk <= AB_KC_MAX),
+                 "kai0_attn_bwd_dq2: needs Q, lse (s_lse >= rows), H >= 1, both or neither mask code, Sk <= %d", AB_KC_MAX);
     KAI0_REQUIRE(HD % 8 == 0 && HD > 0 && HD <= 256, "kai0_attn_bwd_dq: HD=%d unsupported", HD);
     KAI0_REQUIRE(ldo % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldp % 8 == 0 && ldp >= Sk,
                  "kai0_attn_bwd_dq: leading dims must be multiples of 8 and ldp >= Sk");
@@ -232,15 +307,16 @@ KAI0_API int kai0_attn_bwd_dq(const void* dO, const void* O, const void* P, cons
                      (int64_t)rows * ldp * 2 < (int64_t)0x7FFF0000,
                  "kai0_attn_bwd_dq: an operand spans more than 2 GiB per batch entry");
     if (rows <= 0 || Sk <= 0 || batch <= 0) return 0;
-    AbArgs a{(const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)P, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)dS, (bf16_t*)dQ,
-             rows, Sk, HD, ldo, ldk, ldv, ldp, sO, sK, sV, sP, scale};
+    AbArgs a{(const bf16_t*)dO, (const bf16_t*)O, rc ? nullptr : (const bf16_t*)P, rc ? (bf16_t*)P : nullptr, (const bf16_t*)Q, lse,
+             qcode, kcode, s_lse, qcode_ld, kcode_ld, H,
+             (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)dS, (bf16_t*)dQ, rows, Sk, HD, ldo, ldk, ldv, ldp, sO, sK, sV, sP, scale};
     const dim3 grid((rows + 127) / 128, batch, 1);
     hipStream_t s = (hipStream_t)stream;
-#define KAI0_AB_LAUNCH(NKS)                                                                                              \
+#define KAI0_AB_LAUNCH(NKS, RC)                                                                                          \
     do {                                                                                                               \
-        constexpr int LDS = 2 * (NKS * 8192 + 64 * NKS * 128);                                                         \
+        constexpr int LDS = 2 * (NKS * 8192 + 64 * NKS * 128) + (RC ? AB_KC_MAX * 4 : 0);                                \
         static bool attr_set = false;                                                                                  \
-        auto kern = attn_bwd_dq_kernel<NKS>;                                                                           \
+        auto kern = attn_bwd_dq_kernel<NKS, RC>;                                                                       \
         if (!attr_set) {                                                                                               \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);      \
             KAI0_REQUIRE(e == hipSuccess, "kai0_attn_bwd_dq: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e)); \
@@ -248,8 +324,29 @@ KAI0_API int kai0_attn_bwd_dq(const void* dO, const void* O, const void* P, cons
         }                                                                                                              \
         hipLaunchKernelGGL(kern, grid, dim3(512), LDS, s, a);                                                          \
     } while (0)
-    if (HD <= 128) KAI0_AB_LAUNCH(2);
-    else KAI0_AB_LAUNCH(4);
+    if (rc) {
+        if (HD <= 128) KAI0_AB_LAUNCH(2, true);
+        else KAI0_AB_LAUNCH(4, true);
+    } else {
+        if (HD <= 128) KAI0_AB_LAUNCH(2, false);
+        else KAI0_AB_LAUNCH(4, false);
+    }
 #undef KAI0_AB_LAUNCH
     return kai0_check_launch("kai0_attn_bwd_dq");
+}
+
+KAI0_API int kai0_attn_bwd_dq(const void* dO, const void* O, const void* P, const void* K, const void* V, void* dS, void* dQ,
+                              int batch, int rows, int Sk, int HD, int64_t ldo, int64_t ldk, int64_t ldv, int64_t ldp,
+                              int64_t sO, int64_t sK, int64_t sV, int64_t sP, float scale, kai0_stream_t stream) {
+    return attn_bwd_dq_launch(dO, O, P, K, V, dS, dQ, batch, rows, Sk, HD, ldo, ldk, ldv, ldp, sO, sK, sV, sP, scale, stream, nullptr,
+                              nullptr, 0, nullptr, 0, nullptr, 0, 1, false);
+}
+
+KAI0_API int kai0_attn_bwd_desc_size(void) { return (int)sizeof(kai0_attn_bwd_desc); }
+
+KAI0_API int kai0_attn_bwd_dq2(const kai0_attn_bwd_desc* d, kai0_stream_t stream) {
+    KAI0_REQUIRE(d != nullptr, "kai0_attn_bwd_dq2: null descriptor");
+    return attn_bwd_dq_launch(d->dO, d->O, d->P, d->K, d->V, d->dS, d->dQ, d->batch, d->rows, d->Sk, d->HD, d->ldo, d->ldk, d->ldv,
+                              d->ldp, d->sO, d->sK, d->sV, d->sP, d->scale, stream, d->Q, d->lse, d->s_lse, d->qcode, d->qcode_ld,
+                              d->kcode, d->kcode_ld, d->H, true);
 }

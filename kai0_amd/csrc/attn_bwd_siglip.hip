@@ -13,6 +13,10 @@
 //   phase B, wave = 32 keys: dP tiles = MFMA(dO rows permuted, V rows) give lane (key, g) 8 consecutive queries; P^T comes
 //     from a 32-row P chunk in LDS through the transpose read; dK^T += Q^T dS and dV^T += dO^T P take Q^T / dO^T fragments
 //     from the LDS tiles the same way.  No operand is transposed through memory, P is read twice, nothing else is re-read.
+//   RC = true (round 4, kai0_siglip_attn_bwd2): P is not read at all.  Phase A recomputes S^T = K Q^T for the wave's rows from the K
+//     tile in LDS (rows permuted like V's, so the lane layout is dP^T's), phase B recomputes S = Q K^T for the wave's keys from the Q
+//     tile in LDS; both round the logits as the forward does and take P = bf16(exp(s - lse[q])) with the forward's log-sum-exp.
+//     402 MB of P reads per layer (B = 32) and the P staging barriers of phase B are gone, and the forward stores no P.
 #include "common.h"
 #include "../../include/kai0hip.h"
 #include <stdlib.h>
@@ -20,15 +24,19 @@
 namespace {
 
 constexpr int SB_S = 256, SB_HD = 72;
-constexpr int SB_LDR = 104;           // LDS row stride (elements) of the [256][72] tiles: 208 B puts 16 rows on 16 distinct
-                                      // 16-B bank groups; columns 72..103 are zero (MFMA contraction padded to 96, output to 80)
+// LDS row stride (elements) of the [256][72] tiles.  104: 208 B puts 16 rows on 16 distinct 16-B bank groups; columns 72..103 are
+// zero (MFMA contraction padded to 96, output to 80).  72 (RC only): no padding at all — 144-B rows still spread 16 rows over 16
+// distinct 16-B slots (9 r mod 16), the contraction's columns 72..95 read the NEXT row's first elements, which are finite and meet
+// the zero padding of the other operand (always a global-memory fragment), a 64-byte zero guard follows the second tile, and the
+// whole block needs 74.5 KiB: TWO blocks per CU, so one block's staging and barriers hide behind the other's MFMAs.
 constexpr int SB_PLD = 264;           // row stride of a P chunk [32][256]
-constexpr int SB_TILE = SB_S * SB_LDR * 2;         // 53 248 B
 constexpr int SB_PCH = 32 * SB_PLD * 2;            // 16 896 B
-constexpr int SB_LDS = 2 * SB_TILE + 2 * SB_PCH + SB_S * 4;
+constexpr int sb_tile_bytes(int ldr) { return SB_S * ldr * 2; }  // 53 248 B (104) / 36 864 B (72)
+constexpr int sb_lds_bytes(bool rc, int ldr) { return 2 * sb_tile_bytes(ldr) + (rc ? 64 : 2 * SB_PCH) + 2 * SB_S * 4; }
 
 struct SbArgs {
     const bf16_t *q, *k, *v, *dO, *O, *P;
+    const float* lse;  // RC: [n_img * NH][256]
     bf16_t *dq, *dk, *dv;
     int NH;
     int64_t E;   // row stride (elements) of q / k / v / dO / O: NH * 72
@@ -41,23 +49,25 @@ __device__ __forceinline__ bf16x8 sb_zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0
 
 // two [256][72] global tiles (row stride E) -> LDS [256][SB_LDR], pad columns zeroed; 512 threads.  All 2 x 7 loads of a
 // thread are issued before the first LDS store (one global latency per staging, not one per 16-byte chunk).
+template <int SB_LDR>
 __device__ __forceinline__ void sb_stage2(const bf16_t* __restrict__ src0, const bf16_t* __restrict__ src1, int64_t E,
                                           bf16_t* dst0, bf16_t* dst1, int tid) {
-    constexpr int NIT = (SB_S * 13 + 511) / 512;  // 13 chunks of 8 per row: 9 data + 4 zero
+    constexpr int CPR = SB_LDR / 8;                // chunks of 8 per row: 9 data (+ 4 zero when padded)
+    constexpr int NIT = (SB_S * CPR + 511) / 512;
     bf16x8 v0[NIT], v1[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * 512;
-        const int r = idx / 13, c = idx - r * 13;
-        const bool ld = idx < SB_S * 13 && c < 9;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const bool ld = idx < SB_S * CPR && c < 9;
         v0[it] = ld ? *reinterpret_cast<const bf16x8*>(src0 + (int64_t)r * E + c * 8) : sb_zero8();
         v1[it] = ld ? *reinterpret_cast<const bf16x8*>(src1 + (int64_t)r * E + c * 8) : sb_zero8();
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * 512;
-        if (idx < SB_S * 13) {
-            const int r = idx / 13, c = idx - r * 13;
+        if (idx < SB_S * CPR) {
+            const int r = idx / CPR, c = idx - r * CPR;
             *reinterpret_cast<bf16x8*>(dst0 + r * SB_LDR + c * 8) = v0[it];
             *reinterpret_cast<bf16x8*>(dst1 + r * SB_LDR + c * 8) = v1[it];
         }
@@ -65,7 +75,8 @@ __device__ __forceinline__ void sb_stage2(const bf16_t* __restrict__ src0, const
 }
 
 // A/B fragment of a row-major LDS tile, contraction along the row: lane (row, g) <- tile[row][32cc + 8g .. +8]
-__device__ __forceinline__ bf16x8 sb_rowfrag(const bf16_t* tile, int row, int cc, int g) {
+template <int SB_LDR>
+__device__ __forceinline__ bf16x8 sb_rowfrag_t(const bf16_t* tile, int row, int cc, int g) {
     return *reinterpret_cast<const bf16x8*>(tile + row * SB_LDR + 32 * cc + 8 * g);
 }
 // transposed fragment: lane (col c0 + l15, g) <- tile[r0 + 8g .. +8][col]  (two 4x16 transpose reads)
@@ -76,12 +87,21 @@ __device__ __forceinline__ bf16x8 sb_trfrag(const bf16_t* tile, int ld, int r0, 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p) {
+// the reference's logit rounding (bf16(bf16(q k) * scale)) and the probability from the row's log-sum-exp
+__device__ __forceinline__ bf16_t sb_prob(float acc, float scale, float lse) { return f2bf(__expf(rbf(rbf(acc) * scale) - lse)); }
+
+template <bool RC, int SB_LDR>
+__global__ __launch_bounds__(512, (RC && SB_LDR == 72) ? 4 : 1) void siglip_attn_bwd_kernel(const SbArgs p) {
+    static_assert(SB_LDR == 104 || (RC && SB_LDR == 72), "tile row stride");
+    constexpr int SB_TILE = sb_tile_bytes(SB_LDR);
+    auto sb_rowfrag = [](const bf16_t* tile, int row, int cc, int g) { return sb_rowfrag_t<SB_LDR>(tile, row, cc, g); };
     extern __shared__ __attribute__((aligned(16))) char sbm[];
     bf16_t* T0 = reinterpret_cast<bf16_t*>(sbm);                       // phase A: K,  phase B: Q
     bf16_t* T1 = reinterpret_cast<bf16_t*>(sbm + SB_TILE);             // phase A: V,  phase B: dO
     bf16_t* Pc = reinterpret_cast<bf16_t*>(sbm + 2 * SB_TILE);         // [2][32][SB_PLD]
-    float* Dl = reinterpret_cast<float*>(sbm + 2 * SB_TILE + 2 * SB_PCH);
+    float* Dl = reinterpret_cast<float*>(sbm + 2 * SB_TILE + (RC ? 64 : 2 * SB_PCH));
+    if (RC && threadIdx.x < 16) reinterpret_cast<float*>(sbm + 2 * SB_TILE)[threadIdx.x] = 0.f;  // zero guard behind the second tile
+    float* Ll = Dl + SB_S;  // RC: lse of the head's 256 query rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
@@ -113,8 +133,9 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
             for (int e = 0; e < 8; ++e) acc += bf2f(a[i][e]) * bf2f(b[i][e]);
         acc += __shfl_xor(acc, 1, 64);
         if (half == 0) Dl[qr] = acc;
+        if (RC && tid < SB_S) Ll[tid] = p.lse[(int64_t)bh * SB_S + tid];
     }
-    sb_stage2(kg, vg, p.E, T0, T1, tid);
+    sb_stage2<SB_LDR>(kg, vg, p.E, T0, T1, tid);
     __syncthreads();
 
     // ================= phase A: dQ for query rows [32 wave, +32) ==========================================
@@ -131,14 +152,24 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
         const float dq_row = Dl[q0 + l15];
         // this lane's 8 x 8 probabilities of the chunk: all in flight before the first MFMA (the loop is otherwise one
         // global-load latency per key group)
-        bf16x8 pvs[8];
+        bf16x8 pvs[RC ? 1 : 8];
+        bf16x8 qfr[3];
+        float lse_row = 0.f;
+        if constexpr (RC) {
 #pragma unroll
-        for (int kgp = 0; kgp < 8; ++kgp)
-            pvs[kgp] = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)(q0 + l15) * SB_S + 32 * kgp + 8 * g);
+            for (int cc = 0; cc < 3; ++cc)
+                qfr[cc] = (32 * cc + 8 * g) < SB_HD ? *reinterpret_cast<const bf16x8*>(qg + (int64_t)(q0 + l15) * p.E + 32 * cc + 8 * g)
+                                                    : sb_zero8();
+            lse_row = Ll[q0 + l15];
+        } else {
+#pragma unroll
+            for (int kgp = 0; kgp < 8; ++kgp)
+                pvs[kgp] = *reinterpret_cast<const bf16x8*>(Pg + (int64_t)(q0 + l15) * SB_S + 32 * kgp + 8 * g);
+        }
         f32x4 accq[5];
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll RC ? 2 : 8
         for (int kgp = 0; kgp < 8; ++kgp) {
             const int kb = 32 * kgp;
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -148,7 +179,19 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T1, kb + arow + 4, cc, g), dof[cc], a1, 0, 0, 0);
             }
             // lane (q = q0 + l15, g) holds dP for keys kb + 8g + e  (e < 4: a0, e >= 4: a1)
-            const bf16x8 pv = pvs[kgp];
+            bf16x8 pv;
+            if constexpr (RC) {  // S^T for the same (key, q) pairs from the K tile
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T0, kb + arow, cc, g), qfr[cc], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T0, kb + arow + 4, cc, g), qfr[cc], s1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = sb_prob(e < 4 ? s0[e] : s1[e - 4], p.scale, lse_row);
+            } else {
+                pv = pvs[kgp];
+            }
             bf16x8 ds;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ds[e] = f2bf((bf2f(pv[e]) * ((e < 4 ? a0[e] : a1[e - 4]) - dq_row)) * p.scale);
@@ -173,7 +216,68 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
 
     if (p.dbg == 2) return;
     // ================= phase B: dK, dV for keys [32 wave, +32) ============================================
-    sb_stage2(qg, dOg, p.E, T0, T1, tid);
+    sb_stage2<SB_LDR>(qg, dOg, p.E, T0, T1, tid);
+    if constexpr (RC) {
+        // One 16-key tile at a time (the Q / dO fragments of a query chunk are read from LDS once per key tile: the tiles are
+        // read-only in this phase, so there is no barrier inside, and the register budget of two waves per SIMD holds without spills)
+        __syncthreads();
+#pragma unroll 1
+        for (int kt = 0; kt < 2; ++kt) {
+            const int64_t krow = 32 * wave + 16 * kt + l15;
+            bf16x8 kfr[3], vfr[3];  // K / V rows of this tile's keys as B fragments (n = key), straight from global
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const bool in = (32 * cc + 8 * g) < SB_HD;
+                kfr[cc] = in ? *reinterpret_cast<const bf16x8*>(kg + krow * p.E + 32 * cc + 8 * g) : sb_zero8();
+                vfr[cc] = in ? *reinterpret_cast<const bf16x8*>(vg + krow * p.E + 32 * cc + 8 * g) : sb_zero8();
+            }
+            f32x4 acck[5], accv[5];
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) acck[dt] = accv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int qc = 0; qc < 8; ++qc) {
+                const int qb = 32 * qc;
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    // query rows permuted (arow) so that lane (key, g) ends up with queries qb + 8g + e
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T0, qb + arow, cc, g), kfr[cc], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T0, qb + arow + 4, cc, g), kfr[cc], s1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T1, qb + arow, cc, g), vfr[cc], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag(T1, qb + arow + 4, cc, g), vfr[cc], a1, 0, 0, 0);
+                }
+                const f32x4 dv0 = *reinterpret_cast<const f32x4*>(Dl + qb + 8 * g), dv1 = *reinterpret_cast<const f32x4*>(Dl + qb + 8 * g + 4);
+                const f32x4 lv0 = *reinterpret_cast<const f32x4*>(Ll + qb + 8 * g), lv1 = *reinterpret_cast<const f32x4*>(Ll + qb + 8 * g + 4);
+                bf16x8 pt, ds;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    pt[e] = sb_prob(e < 4 ? s0[e] : s1[e - 4], p.scale, e < 4 ? lv0[e] : lv1[e - 4]);
+                    ds[e] = f2bf((bf2f(pt[e]) * ((e < 4 ? a0[e] : a1[e - 4]) - (e < 4 ? dv0[e] : dv1[e - 4]))) * p.scale);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) {
+                    acck[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_trfrag(T0, SB_LDR, qb, 16 * dt, l15, g), ds, acck[dt], 0, 0, 0);
+                    accv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_trfrag(T1, SB_LDR, qb, 16 * dt, l15, g), pt, accv[dt], 0, 0, 0);
+                }
+            }
+            const int64_t ro = gbase + krow * p.Eg;
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) {
+                const int d0 = 16 * dt + 4 * g;
+                if (d0 < SB_HD) {
+                    bf16x4 ok, ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ok[r] = f2bf(acck[dt][r]);
+                        ov[r] = f2bf(accv[dt][r]);
+                    }
+                    *reinterpret_cast<bf16x4*>(p.dk + ro + d0) = ok;
+                    *reinterpret_cast<bf16x4*>(p.dv + ro + d0) = ov;
+                }
+            }
+        }
+        return;
+    }
     // V rows of this wave's keys as B fragments (n = key), straight from global (the LDS copy is gone)
     bf16x8 vfr[2][3];
 #pragma unroll
@@ -266,10 +370,10 @@ __global__ __launch_bounds__(512, 1) void siglip_attn_bwd_kernel(const SbArgs p)
 
 }  // namespace
 
-KAI0_API int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void* dO, const void* O,
-                                  const void* P, void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD,
+static int siglip_attn_bwd_launch(const void* q, const void* k, const void* v, const void* dO, const void* O,
+                                  const void* P, const float* lse, void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD,
                                   int64_t ldp, int64_t ld_grad, float scale, kai0_stream_t stream) {
-    KAI0_REQUIRE(q && k && v && dO && O && P && dq && dk && dv, "kai0_siglip_attn_bwd: null operand");
+    KAI0_REQUIRE(q && k && v && dO && O && (P || lse) && dq && dk && dv, "kai0_siglip_attn_bwd: null operand");
     KAI0_REQUIRE(S == SB_S && HD == SB_HD && ldp == SB_S,
                  "kai0_siglip_attn_bwd: built for S = 256, head_dim = 72, ldp = 256 (got S=%d HD=%d ldp=%lld)", S, HD, (long long)ldp);
     KAI0_REQUIRE(NH >= 1, "kai0_siglip_attn_bwd: NH");
@@ -278,14 +382,37 @@ KAI0_API int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, c
     if (n_img <= 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
-        KAI0_REQUIRE(e == hipSuccess, "kai0_siglip_attn_bwd: cannot reserve %d B of LDS: %s", SB_LDS, hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel<false, 104>, hipFuncAttributeMaxDynamicSharedMemorySize, sb_lds_bytes(false, 104));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel<true, 104>, hipFuncAttributeMaxDynamicSharedMemorySize, sb_lds_bytes(true, 104));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel<true, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, sb_lds_bytes(true, 72));
+        KAI0_REQUIRE(e == hipSuccess, "kai0_siglip_attn_bwd: cannot reserve LDS: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    SbArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)P,
+    SbArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)P, lse,
              (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, NH, (int64_t)NH * HD, ld_grad, scale, 0};
     static const int dbg = [] { const char* e = getenv("KAI0_SB_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
-    hipLaunchKernelGGL(siglip_attn_bwd_kernel, dim3(n_img * NH), dim3(512), SB_LDS, (hipStream_t)stream, a);
+    // KAI0_SB_LDR=104: the padded tiles (one block per CU) for A/B runs
+    static const int ldr = [] { const char* e = getenv("KAI0_SB_LDR"); return e ? atoi(e) : 72; }();
+    if (lse != nullptr && ldr == 72)
+        hipLaunchKernelGGL((siglip_attn_bwd_kernel<true, 72>), dim3(n_img * NH), dim3(512), sb_lds_bytes(true, 72), (hipStream_t)stream, a);
+    else if (lse != nullptr)
+        hipLaunchKernelGGL((siglip_attn_bwd_kernel<true, 104>), dim3(n_img * NH), dim3(512), sb_lds_bytes(true, 104), (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((siglip_attn_bwd_kernel<false, 104>), dim3(n_img * NH), dim3(512), sb_lds_bytes(false, 104), (hipStream_t)stream, a);
     return kai0_check_launch("kai0_siglip_attn_bwd");
+}
+
+KAI0_API int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void* dO, const void* O,
+                                  const void* P, void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD,
+                                  int64_t ldp, int64_t ld_grad, float scale, kai0_stream_t stream) {
+    KAI0_REQUIRE(P != nullptr, "kai0_siglip_attn_bwd: null P");
+    return siglip_attn_bwd_launch(q, k, v, dO, O, P, nullptr, dq, dk, dv, n_img, S, NH, HD, ldp, ld_grad, scale, stream);
+}
+
+KAI0_API int kai0_siglip_attn_bwd2(const void* q, const void* k, const void* v, const void* dO, const void* O,
+                                   const float* lse, void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD,
+                                   int64_t ld_grad, float scale, kai0_stream_t stream) {
+    KAI0_REQUIRE(lse != nullptr, "kai0_siglip_attn_bwd2: null lse");
+    return siglip_attn_bwd_launch(q, k, v, dO, O, nullptr, lse, dq, dk, dv, n_img, S, NH, HD, 256, ld_grad, scale, stream);
 }

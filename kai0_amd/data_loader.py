@@ -20,6 +20,7 @@ must not serialise with the dataset's own decode time)."""
 
 from __future__ import annotations
 
+import logging
 import multiprocessing
 import queue
 import threading
@@ -94,6 +95,28 @@ def _collate_fn(items):
     return _tree_map(lambda *xs: np.stack([np.asarray(x) for x in xs], axis=0), *items)
 
 
+class _SkippingBatchSampler(torch.utils.data.Sampler):
+    """A BatchSampler whose next iterations drop their first `skip` index batches WITHOUT loading them: the sampler's (seeded)
+    index stream is advanced, `dataset.__getitem__` is never called for a dropped batch and no global RNG is consumed."""
+
+    def __init__(self, inner):
+        self.inner, self.skip, self.skipped = inner, 0, 0
+
+    def __len__(self) -> int:
+        return len(self.inner)
+
+    def __iter__(self):
+        it = iter(self.inner)
+        while self.skip > 0:
+            try:
+                next(it)
+            except StopIteration:  # a whole pass dropped: the caller starts the next one (same generator draws as a real pass)
+                return
+            self.skip -= 1
+            self.skipped += 1
+        yield from it
+
+
 class TorchDataLoader:
     def __init__(self, dataset, local_batch_size: int, *, shuffle: bool = False, sampler=None, num_batches: int | None = None,
                  num_workers: int = 0, seed: int = 0):  # fmt: skip
@@ -103,29 +126,36 @@ class TorchDataLoader:
         self._skip = 0
         generator = torch.Generator()
         generator.manual_seed(seed)
+        # the samplers torch.utils.data.DataLoader(batch_size=, shuffle=, sampler=, drop_last=True, generator=) builds itself, made
+        # explicit so that the batch sampler can be advanced without loading (skip_batches); same index stream for the same seed
+        if sampler is None:
+            sampler = (torch.utils.data.RandomSampler(dataset, generator=generator) if shuffle
+                       else torch.utils.data.SequentialSampler(dataset))  # fmt: skip
+        self._batch_sampler = _SkippingBatchSampler(torch.utils.data.BatchSampler(sampler, local_batch_size, drop_last=True))
         self._data_loader = torch.utils.data.DataLoader(
-            dataset, batch_size=local_batch_size, shuffle=(sampler is None and shuffle), sampler=sampler, num_workers=num_workers,
+            dataset, batch_sampler=self._batch_sampler, num_workers=num_workers,
             multiprocessing_context=multiprocessing.get_context("spawn") if num_workers > 0 else None,
-            persistent_workers=num_workers > 0, collate_fn=_collate_fn, drop_last=True, generator=generator)  # fmt: skip
+            persistent_workers=num_workers > 0, collate_fn=_collate_fn, generator=generator)  # fmt: skip
 
     @property
     def torch_loader(self) -> torch.utils.data.DataLoader:
         return self._data_loader
 
     def skip_batches(self, n: int) -> None:
-        """Resume support: the next iteration discards its first `n` batches, i.e. continues the (seeded, hence reproducible)
-        batch stream where a run that had consumed `n` batches stopped.  The skipped batches are still loaded — the order is
-        whatever the sampler and the loader's generator produce, replayed, not re-derived."""
+        """Resume support: the next iteration drops its first `n` batches, i.e. continues the (seeded, hence reproducible) batch
+        stream where a run that had consumed `n` batches stopped.  Dropped at the INDEX level: the batch sampler is advanced, no
+        sample is loaded, decoded or transformed and no global RNG is consumed (resuming at step 20k costs 20k index batches,
+        milliseconds, not 20k global batches of video decoding)."""
         self._skip = max(0, int(n))
 
     def __iter__(self):
         produced = 0
         skip, self._skip = self._skip, 0
+        if skip:
+            logging.getLogger(__name__).info("data loader: skipping %d batches at the index level (resume)", skip)
+        self._batch_sampler.skip = skip
         while True:  # a new pass over the dataset whenever the previous one is exhausted
             for batch in self._data_loader:
-                if skip > 0:
-                    skip -= 1
-                    continue
                 if self._num_batches is not None and produced >= self._num_batches:
                     return
                 produced += 1

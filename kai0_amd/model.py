@@ -586,17 +586,21 @@ class PI0Pytorch(nn.Module):
                 obs.tokenized_prompt_mask, obs.state)  # fmt: skip
 
     @staticmethod
-    def _trim_prompt(lang_tokens, lang_masks):
+    def _trim_prompt(lang_tokens, lang_masks, granule: int = 8):
         """Opt-in (`model.trim_prompt_padding = True` for the training forward, `trim_prompt_padding_infer` for sample_actions): cut
         the prompt to the longest valid prompt of the batch, rounded up to 8 tokens.  The tokenizer pads at the end (tokenizer.py:22-47), padded tokens are invisible as keys
         (`make_att_2d_masks`) and their rows are read by nobody, so the loss and the gradients do not change beyond summation
         order — but every prefix-row GEMM shrinks with the rows (200 slots for 64-128 valid tokens in the bench's synthetic
-        prompts: 968 -> 896 prefix rows).  Costs one scalar device-to-host read per step (the host waits for the stream once)."""
+        prompts: 968 -> 896 prefix rows).  Costs one scalar device-to-host read per step (the host waits for the stream once).
+        `granule`: the kept length is rounded up to a multiple of it.  Training uses 8; the serve path 64, because an inference
+        engine (stacked weight copies + a captured hipGraph) is built per prompt length and pi0.5's discretised state puts a
+        request-dependent number of tokens into the prompt (tokenizer.py:24-29): with 64-token buckets a 200-slot prompt has at
+        most four lengths {64, 128, 192, 200} = `_ENGINE_SLOTS`, so no request rebuilds an engine after warm-up."""
         m = lang_masks.to(torch.bool)
         T = m.shape[1]
         idx = torch.arange(1, T + 1, device=m.device, dtype=torch.int32)
         last = int((m * idx).max().item()) if m.numel() else 0  # exclusive end of the last valid token over the batch
-        keep = min(T, max(8, (last + 7) // 8 * 8))
+        keep = min(T, max(granule, (last + granule - 1) // granule * granule))
         if keep == T:
             return lang_tokens, lang_masks
         return lang_tokens[:, :keep].contiguous(), lang_masks[:, :keep].contiguous()
@@ -684,7 +688,7 @@ class PI0Pytorch(nn.Module):
         if wait is not None:  # a sharded trainer owns the parameters: its in-flight all-gathers must have landed
             wait()
         if self.trim_prompt_padding_infer:
-            lang_tokens, lang_masks = self._trim_prompt(lang_tokens, lang_masks)
+            lang_tokens, lang_masks = self._trim_prompt(lang_tokens, lang_masks, granule=64)
         key = (bsize, lang_tokens.shape[1], len(images))
         eng = self._engine
         if eng is None or not eng.compatible(*key):

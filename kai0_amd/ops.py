@@ -20,7 +20,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc
+from ._lib import AttnBwdDesc, AttnDesc, GemmDesc
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -1209,8 +1209,9 @@ def round_up(x: int, m: int) -> int:
 
 
 def attn_fwd(Q, K, V, O, P, *, rows, Sk, HD, H=1, q0=0, batch=1, batch_inner=1, ldq, ldk, ldv, ldo, ldp=0, sQ=(0, 0),
-             sK=(0, 0), sV=(0, 0), sO=(0, 0), sP=0, qcode=None, kcode=None, scale, q_off=0, o_off=0):
-    """kai0_attn_fwd (fused logits + mask + softmax + P V; optional P output for the backward)."""
+             sK=(0, 0), sV=(0, 0), sO=(0, 0), sP=0, qcode=None, kcode=None, scale, q_off=0, o_off=0, lse=None, online=0):
+    """kai0_attn_fwd (fused logits + mask + softmax + P V).  P: optional probabilities output (the exact two-pass form);
+    lse: optional f32 [batch, >= rows] log-sum-exp output — what the recompute backward needs instead of P."""
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = Q.data_ptr() + 2 * q_off, K.data_ptr(), V.data_ptr(), O.data_ptr() + 2 * o_off
     d.P = _p(P)
@@ -1225,20 +1226,36 @@ def attn_fwd(Q, K, V, O, P, *, rows, Sk, HD, H=1, q0=0, batch=1, batch_inner=1, 
     if qcode is not None:
         d.qcode_ld, d.kcode_ld = qcode.stride(0), kcode.stride(0)
     d.scale = scale
+    d.online = online
+    if lse is not None:
+        _chk(lse, torch.float32, "lse")
+        d.lse, d.s_lse = lse.data_ptr(), lse.stride(0)
     _lib.call("kai0_attn_fwd", C.byref(d), _stream())
 
 
 _ATTN_FWD_GEMM = os.environ.get("KAI0_ATTN_FWD", "fused") == "gemm"
 
 
-def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H, HD, scale, want_probs=True):
+# KAI0_ATTN_STORE_P=1: the round-3 training attention (exact two-pass forward that stores P, backward reads it) for A/B runs
+_ATTN_STORE_P = os.environ.get("KAI0_ATTN_STORE_P", "0") == "1"
+
+
+def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H, HD, scale, want_probs=True, want_lse=False):
     """Prefix-LM masked multi-query attention over padded buffers (modeling_gemma.py:230-253), one fused kernel.
 
     q_all [B, S_ld, H*HD] (query rows q0..q0+Sq used), k_all/v_all [B, S_ld, HD].  The H query heads of a position
     are folded into the row dimension: Q viewed as [Sq*H, HD] per batch entry.
-    Returns (att [B, S_ld, H*HD] with rows q0..q0+Sq written, probs [B, Sq*H, S_ld] or None)."""
+    Returns (att [B, S_ld, H*HD] with rows q0..q0+Sq written, probs [B, Sq*H, S_ld] or None); with want_lse (one-pass forward,
+    no probabilities) the second value is lse f32 [B, Sq*H] instead."""
     dev = q_all.device
     M = Sq * H
+    if want_lse:
+        lse = torch.empty((Bn, M), dtype=torch.float32, device=dev)
+        att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        attn_fwd(q_all, k_all, v_all, att, None, rows=M, Sk=Sk, HD=HD, H=H, q0=q0, batch=Bn, ldq=HD, ldk=HD, ldv=HD, ldo=HD,
+                 sQ=(S_ld * H * HD, 0), sK=(S_ld * HD, 0), sV=(S_ld * HD, 0), sO=(S_ld * H * HD, 0), qcode=qcode, kcode=kcode,
+                 scale=scale, q_off=q0 * H * HD, o_off=q0 * H * HD, lse=lse)
+        return att, lse
     if _ATTN_FWD_GEMM and want_probs and HD % 8 == 0:
         # three launches: logits GEMM (scale in the epilogue), masked softmax in place, P V GEMM
         probs = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
@@ -1306,7 +1323,9 @@ class JointAttentionFn(torch.autograd.Function):
             _copy_rows(vs[i], v_all, Bn, Li, HD, Li * HD, 0, HD, S_ld * HD, r0, HD)
             r0 += Li
         scale = HD**-0.5
-        att, probs = mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, S, 0, S, S_ld, H, HD, scale)
+        # one pass, no stored probabilities: the backward recomputes them from lse (kai0_attn_bwd_dq2)
+        recompute = not _ATTN_STORE_P and not _ATTN_FWD_GEMM and _ATTN_BWD_FUSED and S <= 2048
+        att, probs = mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, S, 0, S, S_ld, H, HD, scale, want_lse=recompute)
         outs = []
         r0 = 0
         for i in range(nseg):
@@ -1315,16 +1334,20 @@ class JointAttentionFn(torch.autograd.Function):
             _copy_rows(att, o, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * H * HD, 0, H * HD)
             outs.append(o)
             r0 += Li
-        ctx.save_for_backward(q_all, k_all, v_all, probs, pos, inv_freq, att)
-        ctx.cfg = (Bn, S, S_ld, H, HD, seg_lens, scale)
+        ctx.save_for_backward(q_all, k_all, v_all, probs, pos, inv_freq, att, qcode, kcode)
+        ctx.cfg = (Bn, S, S_ld, H, HD, seg_lens, scale, recompute)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        q_all, k_all, v_all, probs, pos, inv_freq, att = ctx.saved_tensors
-        Bn, S, S_ld, H, HD, seg_lens, scale = ctx.cfg
+        q_all, k_all, v_all, probs, pos, inv_freq, att, qcode, kcode = ctx.saved_tensors
+        Bn, S, S_ld, H, HD, seg_lens, scale, recompute = ctx.cfg
         dev = q_all.device
         M = S * H
+        dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
+        if recompute:
+            lse, probs = probs, torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
+            dscores = torch.empty_like(probs)
         datt = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
         if S_ld > S:
             datt[:, S:].zero_()
@@ -1332,6 +1355,19 @@ class JointAttentionFn(torch.autograd.Function):
         for i, Li in enumerate(seg_lens):
             _copy_rows(douts[i].contiguous(), datt, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
             r0 += Li
+        if recompute:
+            # query side first: it (re)produces P for the dV GEMM below — S, P = exp(S - lse), dP, dS, dQ in one launch
+            d = AttnBwdDesc()
+            d.dO, d.O, d.Q, d.K, d.V = datt.data_ptr(), att.data_ptr(), q_all.data_ptr(), k_all.data_ptr(), v_all.data_ptr()
+            d.lse, d.qcode, d.kcode = lse.data_ptr(), _p(qcode), _p(kcode)
+            d.P, d.dS, d.dQ = probs.data_ptr(), dscores.data_ptr(), dq_all.data_ptr()
+            d.batch, d.rows, d.Sk, d.HD, d.H = Bn, M, S, HD, H
+            d.ldo, d.ldk, d.ldv, d.ldp = HD, HD, HD, S_ld
+            d.sO, d.sK, d.sV, d.sP, d.s_lse = S_ld * H * HD, S_ld * HD, S_ld * HD, M * S_ld, lse.stride(0)
+            if qcode is not None:
+                d.qcode_ld, d.kcode_ld = qcode.stride(0), kcode.stride(0)
+            d.scale = scale
+            _lib.call("kai0_attn_bwd_dq2", C.byref(d), _stream())
         # dV[b] [S_ld, HD] = P[b]^T [S_ld, M] @ dO[b] [M, HD]
         # (few output tiles per sample, long contraction over the M = S*H folded rows: split it so that the 256x256 ring
         # schedule gets a block per CU instead of falling back to 128x128 tiles — 578 -> ~1000 TFLOP/s)
@@ -1342,9 +1378,11 @@ class JointAttentionFn(torch.autograd.Function):
         # dS[b] [M, S_ld] = softmax'(dP), dP[b] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K]): the softmax
         # backward runs in the GEMM epilogue on the f32 accumulator (dP is never rounded or written; the row term
         # <dP, P> is computed as rowsum(dO * O), kai0hip.h act 4)
-        dscores = torch.empty_like(probs)
-        dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-        if _ATTN_BWD_FUSED:
+        if not recompute:
+            dscores = torch.empty_like(probs)
+        if recompute:
+            pass
+        elif _ATTN_BWD_FUSED:
             # one launch: D = rowsum(dO * O), dP = dO V^T in f32, dS written once, dQ = dS K accumulated on chip
             _lib.call("kai0_attn_bwd_dq", datt.data_ptr(), att.data_ptr(), probs.data_ptr(), k_all.data_ptr(), v_all.data_ptr(),
                       dscores.data_ptr(), dq_all.data_ptr(), Bn, M, S, HD, HD, HD, HD, S_ld, S_ld * H * HD, S_ld * HD, S_ld * HD,
@@ -1354,7 +1392,7 @@ class JointAttentionFn(torch.autograd.Function):
             gemm(datt, v_all, dscores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
                  sB=(S_ld * HD, 0), sC=(M * S_ld, 0), act=4, aux1=probs, rowvec=dsum, rv=(S_ld * H, 0, 1), scale=scale)  # fmt: skip
         # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
-        if _ATTN_BWD_FUSED:
+        if _ATTN_BWD_FUSED or recompute:
             pass
         elif _ATTN_BWD_NT and S_ld % 8 == 0:
             # through K^T (0.5 MB per sample to transpose): both operands contraction-contiguous -> the NT quadrant schedule
@@ -1401,21 +1439,33 @@ class SiglipAttentionFn(torch.autograd.Function):
         E = NH * HD
         S_ld = round_up(S, 8)
         scale = HD**-0.5
-        probs = torch.empty((n_img * NH, S, S_ld), dtype=BF16, device=dev)
         out = torch.empty((n_img * S, E), dtype=BF16, device=dev)
-        attn_fwd(q, k, v, out, probs, rows=S, Sk=S, HD=HD, H=1, batch=n_img * NH, batch_inner=NH, ldq=E, ldk=E, ldv=E,
-                 ldo=E, ldp=S_ld, sQ=(S * E, HD), sK=(S * E, HD), sV=(S * E, HD), sO=(S * E, HD), sP=S * S_ld, scale=scale)
+        # the real tower: no stored probabilities, the fused backward recomputes them from lse (kai0_siglip_attn_bwd2)
+        recompute = S == 256 and HD == 72 and S_ld == 256 and _SIGLIP_BWD_FUSED and not _ATTN_STORE_P
+        if recompute:
+            probs = torch.empty((n_img * NH, S), dtype=torch.float32, device=dev)  # lse
+            attn_fwd(q, k, v, out, None, rows=S, Sk=S, HD=HD, H=1, batch=n_img * NH, batch_inner=NH, ldq=E, ldk=E, ldv=E, ldo=E,
+                     sQ=(S * E, HD), sK=(S * E, HD), sV=(S * E, HD), sO=(S * E, HD), scale=scale, lse=probs)
+        else:
+            probs = torch.empty((n_img * NH, S, S_ld), dtype=BF16, device=dev)
+            attn_fwd(q, k, v, out, probs, rows=S, Sk=S, HD=HD, H=1, batch=n_img * NH, batch_inner=NH, ldq=E, ldk=E, ldv=E,
+                     ldo=E, ldp=S_ld, sQ=(S * E, HD), sK=(S * E, HD), sV=(S * E, HD), sO=(S * E, HD), sP=S * S_ld, scale=scale)
         ctx.save_for_backward(q, k, v, probs, out)
-        ctx.cfg = (n_img, S, S_ld, NH, HD, scale)
+        ctx.cfg = (n_img, S, S_ld, NH, HD, scale, recompute)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, probs, out = ctx.saved_tensors
-        n_img, S, S_ld, NH, HD, scale = ctx.cfg
+        n_img, S, S_ld, NH, HD, scale, recompute = ctx.cfg
         dev = q.device
         E = NH * HD
         dout = dout.contiguous()
+        if recompute:
+            dq, dk, dv = fused_columns(q.shape[0], (E, E, E), dev)
+            _lib.call("kai0_siglip_attn_bwd2", q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), out.data_ptr(),
+                      probs.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), n_img, S, NH, HD, 3 * E, scale, _stream())  # fmt: skip
+            return dq, dk, dv, None, None, None, None
         if S == 256 and HD == 72 and S_ld == 256 and _SIGLIP_BWD_FUSED:
             # the real tower (so400m/14 @ 224): one block per (image, head) runs the whole backward out of LDS
             # dq | dk | dv are the column slices of one buffer: the fused q|k|v projection backward reads it whole

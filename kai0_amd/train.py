@@ -143,7 +143,17 @@ class Trainer:
         # tensors, numbers, lists and strings only: no pickle execution from a checkpoint directory
         opt = torch.load(os.path.join(d, "optimizer.pt"), map_location="cpu", weights_only=True)
         self.engine.load_state_dict(opt, self._param_order)
-        meta = torch.load(os.path.join(d, "metadata.pt"), map_location="cpu", weights_only=True)
+        # metadata.pt written by the REFERENCE holds dataclasses.asdict(config) (train_pytorch.py:172-177): model / transform classes,
+        # nnx.Nothing() ... which the weights-only unpickler refuses.  Only global_step (and this trainer's rng_state) are needed:
+        # fall back to the directory name, never to weights_only=False.
+        import pickle
+
+        try:
+            meta = torch.load(os.path.join(d, "metadata.pt"), map_location="cpu", weights_only=True)
+        except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError, FileNotFoundError) as e:
+            logging.getLogger(__name__).warning("metadata.pt of %s not loadable weights-only (%s): step taken from the directory name, "
+                                                "no RNG state", d, type(e).__name__)  # fmt: skip
+            meta = {}
         self.global_step = int(meta.get("global_step", step))
         self.resumed_rng_state = meta.get("rng_state")  # train_loop restores it when the world size is the one that wrote it
         if getattr(self.model, "_engine", None) is not None:
