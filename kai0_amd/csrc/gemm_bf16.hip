@@ -1353,13 +1353,14 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // measured (MLP shapes, random data): the ring wins +21 % for the transpose-read layout (TN wgrads: 512-B source rows,
     // so a 32-deep sub-tile still moves whole cache lines) and loses up to 17 % for NT (64-B source rows = half lines,
     // every line crosses the fabric twice), which keeps the two-buffer ping-pong.
-    const bool ring = forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc);
+    // (act 6 selects its second weight per DMA piece of a 64-deep K-tile: it never runs on the 32-deep ring, whatever is forced)
+    const bool ring = d->act != 6 && (forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc));
     // forced 8: 384x256x64 plain loop (NT / NN only): 20 % fewer staged bytes per FLOP than 256x256
     // forced 9 / 10: the quadrant schedule for NT (DMA pieces after the fragment reads / between the MFMAs), others as picked
     if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
     else if (forced == 9) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
     else if (forced == 10) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);
-    else if (forced == 11 && !d->a_kc && !d->b_kc) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);  // the former ring: two of a sub-tile's four DMA pieces in the load slot
+    else if (forced == 11 && !d->a_kc && !d->b_kc && d->act != 6) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);  // the former ring: two of a sub-tile's four DMA pieces in the load slot
     // ring with every DMA piece (and its offset arithmetic) between the MFMA rows: +0.9 % over two pieces per slot kind on the TN shapes
     else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32, 3>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);

@@ -493,6 +493,7 @@ class PI0Pytorch(nn.Module):
         # 10-40 of pi0.5's 200 slots).  Off here — the model computes what the reference computes; policy.create_trained_policy turns
         # it on for the serve path.  Engines are kept per (batch, prompt slots, cameras), a few at a time (_ENGINE_SLOTS).
         self.trim_prompt_padding_infer = False
+        self.trim_prompt_granule_infer = 64  # serve path: prompt lengths are bucketed (see _trim_prompt)
         self._engine = None
 
     # ---- reference API ------------------------------------------------------------------------------------
@@ -688,7 +689,7 @@ class PI0Pytorch(nn.Module):
         if wait is not None:  # a sharded trainer owns the parameters: its in-flight all-gathers must have landed
             wait()
         if self.trim_prompt_padding_infer:
-            lang_tokens, lang_masks = self._trim_prompt(lang_tokens, lang_masks, granule=64)
+            lang_tokens, lang_masks = self._trim_prompt(lang_tokens, lang_masks, granule=self.trim_prompt_granule_infer)
         key = (bsize, lang_tokens.shape[1], len(images))
         eng = self._engine
         if eng is None or not eng.compatible(*key):

@@ -331,6 +331,9 @@ def _grad_dst(param, dtype):
     sharded.py (`_kai0_grad_out`, so no copy is needed afterwards) or a fresh tensor."""
     dst = getattr(param, "_kai0_grad_out", None)
     if dst is not None and dst.shape == param.shape and dst.dtype == dtype:
+        ensure = getattr(param, "_kai0_grad_ensure", None)
+        if ensure is not None:
+            ensure()  # fsdp staging buffer: make sure its storage exists (sharded.py _ensure_grad; a no-op when resident)
         return dst
     return torch.empty(param.shape, dtype=dtype, device=param.device)
 

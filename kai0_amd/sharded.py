@@ -238,6 +238,9 @@ class ShardedDataParallel:
                 self._where[p] = (b, o)
                 p.register_post_accumulate_grad_hook(self._on_grad)
                 p._kai0_grad_done = functools.partial(self._on_grad_inplace, p)
+                # fsdp: the flat gradient buffer is a staging buffer that may be given back between uses; a producer that is about
+                # to write into `_kai0_grad_out` calls this first (ops._grad_dst), so the view never points at a 0-byte storage
+                p._kai0_grad_ensure = functools.partial(self._ensure_grad, b)
         self._bucket_group = {}
         for g, ids in enumerate(self.groups):
             for bi in ids:
@@ -388,6 +391,23 @@ class ShardedDataParallel:
         """Called at the start of every training step: state that an aborted backward (an exception, an evaluation with
         gradients but no step()) may have left behind does not leak into this step."""
         self._in_backward = False
+        # a backward that did not reach step(): drop its collectives and its bucket bookkeeping, or this step would raise "a
+        # parameter received two gradients", launch a reduce-scatter on stale counts, or retire a dead work handle (ADVICE r3)
+        for b in self._rs_inflight:
+            if b.rs_work is not None:
+                self._wait(b.rs_work, "reduce_scatter_wait")
+                b.rs_work = None
+        self._rs_inflight.clear()
+        for b in self.buckets:
+            if b.rs_work is not None:
+                self._wait(b.rs_work, "reduce_scatter_wait")
+                b.rs_work = None
+            if b.arrived or b.pending != len(b.params):
+                if b.grad_resident:  # the aborted step's partial gradients must not be taken for this step's
+                    b.stale.update(b.arrived)
+                b.arrived.clear()
+                b.pending = len(b.params)
+            b.announced = False
         if self.device.type == "cuda":
             from . import ops
 

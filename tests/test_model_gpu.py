@@ -505,6 +505,8 @@ def test_trimmed_prompt_gives_the_same_action_chunk_and_engines_are_kept_per_sha
         e_full = m._engine
         assert e_full.T == mask.shape[1]
         m.trim_prompt_padding_infer = True
+        assert m.trim_prompt_granule_infer == 64  # serve default: 64-token buckets, at most four engine shapes for 200 slots
+        m.trim_prompt_granule_infer = 8           # (the tiny fixture's prompt is shorter than one bucket)
         trimmed = m.sample_actions(dev, obs, noise=noise, num_steps=10)
         e_trim = m._engine
         assert e_trim is not e_full and e_trim.T < e_full.T and e_trim.T % 8 == 0 and e_trim.T >= int(mask.sum(1).max())
@@ -526,6 +528,7 @@ def test_trimmed_prompt_gives_the_same_action_chunk_and_engines_are_kept_per_sha
         assert m._engine is None and not m.__dict__["_engine_lru"]
     finally:
         m.trim_prompt_padding_infer = False
+        m.trim_prompt_granule_infer = 64
         m.invalidate_inference_engine()
         m.train()
 

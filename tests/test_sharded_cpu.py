@@ -354,6 +354,36 @@ def test_sharded_engine_world1_equals_reference():
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-5)
 
 
+def test_begin_step_drops_the_state_of_an_aborted_backward():
+    """A backward that never reached step() (an exception, an evaluation with gradients) leaves arrived / pending counts and
+    gradients behind; begin_step() must reset them: the next full step equals a clean engine's, and a parameter that gets no new
+    gradient afterwards counts as zero, not as the aborted step's value."""
+    from kai0_amd.sharded import ShardedDataParallel
+
+    model, ref = _toy_model(), _toy_model()
+    eng = ShardedDataParallel(model.parameters(), world_size=1, rank=0, ops=TorchShardOps(), weight_decay=0.0, max_grad_norm=1.0,
+                              bucket_bytes=1024)  # fmt: skip
+    ropt = torch.optim.AdamW(ref.parameters(), lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0)
+    x = torch.randn(5, 24)
+    (model(x).pow(2).mean() * 7.0).backward()  # aborted: no step()
+    assert any(b.arrived for b in eng.buckets)
+    eng.begin_step()
+    assert all(not b.arrived and b.pending == len(b.params) and b.rs_work is None for b in eng.buckets)
+    # only the first Linear gets a gradient now (the second is detached from the loss): its slice must not keep the aborted one
+    model[0](x).pow(2).mean().backward()
+    eng.step(3e-3)
+    ref.zero_grad()
+    ref[0](x).pow(2).mean().backward()
+    torch.nn.utils.clip_grad_norm_([q for q in ref.parameters() if q.grad is not None], 1.0)
+    ropt.step()
+    for p, r in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p, r, atol=2e-6, rtol=1e-5)
+    # and a clean step after that
+    eng.begin_step()
+    model(x).pow(2).mean().backward()
+    eng.step(3e-3)
+
+
 def test_weights_written_after_construction_are_adopted_or_reported():
     """ADVICE r1: the f32 master copies are cut at construction.  In-place writes + sync_master_from_params() are adopted;
     rebinding p.data (a dtype cast, .to()) detaches the parameter from the flat buffer and the next step says so."""
