@@ -352,6 +352,14 @@ int kai0_siglip_attn_bwd(const void* q, const void* k, const void* v, const void
                          float scale, kai0_stream_t stream);
 /* The same without stored probabilities (round 4): P = bf16(exp(bf16(bf16(q k^T) * scale) - lse[row])) is recomputed inside the
  * block from the q / k tiles that are in LDS anyway; lse: f32 [n_img * NH][S] from kai0_attn_fwd (kai0_attn_desc.lse). */
+/* SigLIP's attention forward at the real tower's shape (S = 256 tokens, head_dim = 72; modeling_siglip.py:325-345), one block per
+ * (image, head) with the head's K and V unpadded in LDS: logits = bf16(bf16(q k^T) * scale), EXACT softmax in f32 (the whole row is
+ * on chip), P = bf16(softmax), O = bf16(P V) — the reference's rounding order, in one pass, no P written.
+ *   q, k, v: bf16, row r of image n at q + n * sq + r * ldq, head h at column h * 72 (the three may be column slices of one stacked
+ *   q|k|v buffer); o likewise (so, ldo); lse: optional f32 [n_img * NH][256] for kai0_siglip_attn_bwd2. */
+int kai0_siglip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int n_img, int S, int NH, int HD,
+                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so,
+                         float scale, kai0_stream_t stream);
 int kai0_siglip_attn_bwd2(const void* q, const void* k, const void* v, const void* dO, const void* O, const float* lse,
                           void* dq, void* dk, void* dv, int n_img, int S, int NH, int HD, int64_t ld_grad, float scale,
                           kai0_stream_t stream);

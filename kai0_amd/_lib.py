@@ -108,6 +108,7 @@ _PROTOS: dict[str, list] = {
     "kai0_attn_desc_size": [],
     "kai0_attn_bwd_dq2": [C.POINTER(AttnBwdDesc), c_p],
     "kai0_attn_bwd_desc_size": [],
+    "kai0_siglip_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_p],
     "kai0_siglip_attn_bwd2": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_f, c_p],
     "kai0_gemm_skinny_bf16": [C.POINTER(SkinnyDesc), c_p],
     "kai0_skinny_desc_size": [],

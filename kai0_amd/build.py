@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = pathlib.Path(__file__).resolve().parent
-SRC = ["runtime.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "skinny.hip", "attn_decode.hip", "attn_bwd_siglip.hip", "attn_bwd.hip", "norm.hip", "elementwise.hip", "optim.hip"]
+SRC = ["runtime.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "skinny.hip", "attn_decode.hip", "attn_siglip.hip", "attn_bwd.hip", "norm.hip", "elementwise.hip", "optim.hip"]
 OUT = HERE / "lib" / "libkai0hip.so"
 
 

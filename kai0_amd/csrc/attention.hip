@@ -7,7 +7,7 @@
 //   * training (round 4): ONE pass with an online softmax (OP = -1): per key tile the logits are computed once, the running row
 //     max m and row sum l are updated, O is rescaled by exp(m_old - m_new) when a row's max moved, P~ = bf16(exp(s - m)) goes
 //     straight into P V; at the end O /= l and lse = m + log(l) is written per row.  NO probabilities leave the chip: the
-//     backward recomputes them from Q, K and lse (attn_bwd.hip, attn_bwd_siglip.hip).  The logits keep the reference's rounding
+//     backward recomputes them from Q, K and lse (attn_bwd.hip, attn_siglip.hip).  The logits keep the reference's rounding
 //     (bf16(bf16(Q K^T) * scale)); the point where P is rounded to bf16 moves from "after the normalisation" to "before" —
 //     inside the stated floating-point tolerance, not bit-identical to eager_attention_forward.
 //   * the former "two-pass" form (OP = 0: pass 1 row max / row sum, pass 2 recomputes the logits, writes the FINAL normalised P

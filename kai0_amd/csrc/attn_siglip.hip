@@ -1,5 +1,5 @@
-// attn_bwd_siglip.hip — backward of SigLIP's unmasked multi-head attention (modeling_siglip.py:325-345 through autograd),
-// one block per (image, head): S = 256 tokens, HD = 72.
+// attn_siglip.hip — SigLIP's unmasked multi-head attention (modeling_siglip.py:325-345), forward and backward, one block per
+// (image, head): S = 256 tokens, HD = 72.  The backward first (rounds 2-4), the forward (round 4) at the end of the file.
 //
 // The GEMM formulation spent 4 batched launches per layer on 1536 tiny problems (256x256x72: two K-tiles each, all
 // prologue / epilogue) — ~0.57 ms per layer for 58 GFLOP.  Here a head's whole backward runs out of one block's LDS:
@@ -368,6 +368,134 @@ __global__ __launch_bounds__(512, (RC && SB_LDR == 72) ? 4 : 1) void siglip_attn
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward (round 4).  The general kernel (attention.hip) pads the head dim 72 -> 128 (1.8x the MFMA work and the LDS traffic) and
+// runs one 144-KiB block per CU; here a head's K and V sit unpadded in 74.5 KiB of LDS (two blocks per CU) and the whole row of
+// logits of a query is on chip at once, so the softmax is EXACT (row max, row sum, P = bf16(softmax) — the reference's rounding
+// order) in a single pass:
+//   wave = 16 query rows at a time: S^T = K Q^T in 8 groups of 32 keys (K rows permuted so that lane (q, g) holds 8 consecutive
+//   keys of the group = the B fragment of O^T += V^T P^T), V^T fragments through the transpose read of the row-major V tile.
+// <NWV waves, CH 16-row chunks per wave>: <8, 2> = a whole head (256 rows) per block (training: 1536 blocks, two per CU), <4, 2> two
+// blocks per head (A/B), <4, 1> four 64-row blocks per head (B = 1 inference: 48 heads then cover 192 CUs).  lse (optional) = log-sum-exp of the rounded logits, for the recompute backward.
+struct SfArgs {
+    const bf16_t *q, *k, *v;
+    bf16_t* o;
+    float* lse;
+    int NH;
+    int64_t ldq, ldk, ldv, ldo;      // row strides (elements); q / k / v may be column slices of one stacked buffer
+    int64_t sq, sk, sv, so;          // per-image strides
+    float scale;
+};
+
+template <int NWV, int CH>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void siglip_attn_fwd_kernel(const SfArgs p) {
+    constexpr int LDR = 72, NT = NWV * 64, RB = NWV * 16 * CH;
+    constexpr int TILE = sb_tile_bytes(LDR);
+    extern __shared__ __attribute__((aligned(16))) char sfm[];
+    bf16_t* T0 = reinterpret_cast<bf16_t*>(sfm);          // K
+    bf16_t* T1 = reinterpret_cast<bf16_t*>(sfm + TILE);   // V
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, n = bh / p.NH, h = bh - n * p.NH;
+    const bf16_t* qg = p.q + (int64_t)n * p.sq + (int64_t)h * SB_HD;
+    const bf16_t* kg = p.k + (int64_t)n * p.sk + (int64_t)h * SB_HD;
+    const bf16_t* vg = p.v + (int64_t)n * p.sv + (int64_t)h * SB_HD;
+    bf16_t* og = p.o + (int64_t)n * p.so + (int64_t)h * SB_HD;
+    if (tid < 16) reinterpret_cast<float*>(sfm + 2 * TILE)[tid] = 0.f;  // zero guard behind the V tile (see LDR = 72 above)
+    // K and V tiles: [256][72] each, 9 chunks of 16 B per row, every load of the thread in flight before the first LDS store
+    {
+        constexpr int NIT = (SB_S * 9 + NT - 1) / NT;
+        bf16x8 a[NIT], b[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = min(tid + it * NT, SB_S * 9 - 1);  // clamped, not guarded (a guarded load is a branch with its own wait)
+            const int r = idx / 9, c = idx - r * 9;
+            a[it] = *reinterpret_cast<const bf16x8*>(kg + (int64_t)r * p.ldk + c * 8);
+            b[it] = *reinterpret_cast<const bf16x8*>(vg + (int64_t)r * p.ldv + c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < SB_S * 9) {
+                const int r = idx / 9, c = idx - r * 9;
+                *reinterpret_cast<bf16x8*>(T0 + r * LDR + c * 8) = a[it];
+                *reinterpret_cast<bf16x8*>(T1 + r * LDR + c * 8) = b[it];
+            }
+        }
+    }
+    const int arow = 8 * (l15 >> 2) + (l15 & 3);  // key of a 32-key group fed to A-row l15 of tile 0 (tile 1: + 4)
+    const int qrow0 = blockIdx.y * RB + wave * (16 * CH);
+    __syncthreads();
+    // (fully unrolled: inside a rolled loop hipcc hoists the ~130 loop-invariant LDS addresses into registers and spills them)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int q0 = qrow0 + 16 * c;
+        // Q fragments of the chunk straight from global (B operand: lane (q, g) <- Q[q][32 cc + 8 g .. + 8], zero past 72)
+        bf16x8 qf[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            qf[cc] = (32 * cc + 8 * g) < SB_HD ? *reinterpret_cast<const bf16x8*>(qg + (int64_t)(q0 + l15) * p.ldq + 32 * cc + 8 * g) : sb_zero8();
+        // logits of the row's 256 keys: lane (q, g) holds keys 32 kgp + 8 g + e
+        float s[8][8];
+#pragma unroll
+        for (int kgp = 0; kgp < 8; ++kgp) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag_t<LDR>(T0, 32 * kgp + arow, cc, g), qf[cc], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_rowfrag_t<LDR>(T0, 32 * kgp + arow + 4, cc, g), qf[cc], s1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[kgp][e] = rbf(rbf(e < 4 ? s0[e] : s1[e - 4]) * p.scale);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kgp = 0; kgp < 8; ++kgp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, s[kgp][e]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kgp = 0; kgp < 8; ++kgp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s[kgp][e] = __expf(s[kgp][e] - m);
+                l += s[kgp][e];
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv_l = 1.0f / l;
+        if (p.lse != nullptr && g == 0) p.lse[(int64_t)bh * SB_S + q0 + l15] = m + __logf(l);
+        f32x4 acc[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kgp = 0; kgp < 8; ++kgp) {
+            bf16x8 pv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = f2bf(s[kgp][e] * inv_l);  // P = bf16(softmax): what the reference multiplies V with
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt)
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_trfrag(T1, LDR, 32 * kgp, 16 * dt, l15, g), pv, acc[dt], 0, 0, 0);
+        }
+        // acc[dt]: lane (q = q0 + l15, g) holds d = 16 dt + 4 g + r
+        bf16_t* op = og + (int64_t)(q0 + l15) * p.ldo;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < SB_HD) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = f2bf(acc[dt][r]);
+                *reinterpret_cast<bf16x4*>(op + d0) = ov;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int siglip_attn_bwd_launch(const void* q, const void* k, const void* v, const void* dO, const void* O,
@@ -415,4 +543,34 @@ KAI0_API int kai0_siglip_attn_bwd2(const void* q, const void* k, const void* v, 
                                    int64_t ld_grad, float scale, kai0_stream_t stream) {
     KAI0_REQUIRE(lse != nullptr, "kai0_siglip_attn_bwd2: null lse");
     return siglip_attn_bwd_launch(q, k, v, dO, O, nullptr, lse, dq, dk, dv, n_img, S, NH, HD, 256, ld_grad, scale, stream);
+}
+
+/* kai0_siglip_attn_fwd: see kai0hip.h */
+KAI0_API int kai0_siglip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int n_img, int S, int NH, int HD,
+                                  int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so,
+                                  float scale, kai0_stream_t stream) {
+    KAI0_REQUIRE(q && k && v && o, "kai0_siglip_attn_fwd: null operand");
+    KAI0_REQUIRE(S == SB_S && HD == SB_HD && NH >= 1, "kai0_siglip_attn_fwd: built for S = 256, head_dim = 72 (got S=%d HD=%d)", S, HD);
+    KAI0_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0 && ((uintptr_t)o % 8) == 0,
+                 "kai0_siglip_attn_fwd: q / k / v rows must be 16-byte aligned (leading dims %% 8), o rows 8-byte aligned");
+    if (n_img <= 0) return 0;
+    constexpr int LDS = 2 * sb_tile_bytes(72) + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        KAI0_REQUIRE(e == hipSuccess, "kai0_siglip_attn_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    SfArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, NH, ldq, ldk, ldv, ldo, sq, sk, sv, so, scale};
+    const int heads = n_img * NH;
+    // few heads (B = 1 inference: 48): four 64-row blocks per head so that the launch covers the chip
+    // KAI0_SF_ROWS=128: two four-wave blocks per head instead of one eight-wave block (A/B)
+    static const int rows = [] { const char* e = getenv("KAI0_SF_ROWS"); return e ? atoi(e) : 256; }();
+    if (heads <= 128) hipLaunchKernelGGL((siglip_attn_fwd_kernel<4, 1>), dim3(heads, 4), dim3(256), LDS, (hipStream_t)stream, a);
+    else if (rows == 128) hipLaunchKernelGGL((siglip_attn_fwd_kernel<4, 2>), dim3(heads, 2), dim3(256), LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((siglip_attn_fwd_kernel<8, 2>), dim3(heads, 1), dim3(512), LDS, (hipStream_t)stream, a);
+    return kai0_check_launch("kai0_siglip_attn_fwd");
 }

@@ -183,9 +183,12 @@ class InferenceEngine:
         for l, layer in enumerate(layers):
             qkv = self._lin(h, self.sg_wqkv[l], bias=self.sg_bqkv[l])
             a = torch.empty((n * S, E), dtype=BF16, device=self.dev)
-            ops.attn_fwd(qkv, qkv[:, E:], qkv[:, 2 * E:], a, None, rows=S, Sk=S, HD=HD, H=1, batch=n * NH, batch_inner=NH,
-                         ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, sQ=(S * 3 * E, HD), sK=(S * 3 * E, HD), sV=(S * 3 * E, HD),
-                         sO=(S * E, HD), scale=scale)  # fmt: skip
+            if S == 256 and HD == 72 and ops._SIGLIP_FWD_DEDICATED:  # the real tower: head-resident kernel, exact one-pass softmax
+                ops.siglip_attn_fwd(qkv, qkv[:, E:], qkv[:, 2 * E:], a, n_img=n, S=S, NH=NH, HD=HD, ld_qkv=3 * E, ld_out=E)
+            else:
+                ops.attn_fwd(qkv, qkv[:, E:], qkv[:, 2 * E:], a, None, rows=S, Sk=S, HD=HD, H=1, batch=n * NH, batch_inner=NH,
+                             ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, sQ=(S * 3 * E, HD), sK=(S * 3 * E, HD), sV=(S * 3 * E, HD),
+                             sO=(S * E, HD), scale=scale)  # fmt: skip
             # each norm is handed to the Linear that produces its input (out_proj -> layer_norm2, fc2 -> the next layer's layer_norm1 /
             # the post-layernorm): split-K Linears run it inside their reduction launch
             ln2 = layer.layer_norm2

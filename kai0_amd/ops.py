@@ -1431,6 +1431,14 @@ def joint_attention(pos, qcode, kcode, inv_freq, H, HD, seg_lens, qkv):
 
 
 _SIGLIP_BWD_FUSED = os.environ.get("KAI0_SIGLIP_BWD", "fused") != "gemm"
+_SIGLIP_FWD_DEDICATED = os.environ.get("KAI0_SIGLIP_FWD", "dedicated") != "general"  # (general: kai0_attn_fwd, A/B)
+
+
+def siglip_attn_fwd(q, k, v, out, *, n_img, S, NH, HD, ld_qkv, ld_out, lse=None):
+    """kai0_siglip_attn_fwd: the real tower's attention (256 tokens, head_dim 72), one block per (image, head), exact softmax in one
+    pass.  q / k / v: [n_img * S, >= NH * HD] bf16 views with row stride ld_qkv (column slices of a stacked buffer allowed)."""
+    _lib.call("kai0_siglip_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _p(lse), n_img, S, NH, HD, ld_qkv,
+              ld_qkv, ld_qkv, ld_out, S * ld_qkv, S * ld_qkv, S * ld_qkv, S * ld_out, HD**-0.5, _stream())
 
 
 class SiglipAttentionFn(torch.autograd.Function):
@@ -1445,7 +1453,10 @@ class SiglipAttentionFn(torch.autograd.Function):
         out = torch.empty((n_img * S, E), dtype=BF16, device=dev)
         # the real tower: no stored probabilities, the fused backward recomputes them from lse (kai0_siglip_attn_bwd2)
         recompute = S == 256 and HD == 72 and S_ld == 256 and _SIGLIP_BWD_FUSED and not _ATTN_STORE_P
-        if recompute:
+        if recompute and _SIGLIP_FWD_DEDICATED and q.stride(0) == k.stride(0) == v.stride(0):
+            probs = torch.empty((n_img * NH, S), dtype=torch.float32, device=dev)  # lse
+            siglip_attn_fwd(q, k, v, out, n_img=n_img, S=S, NH=NH, HD=HD, ld_qkv=q.stride(0), ld_out=E, lse=probs)
+        elif recompute:
             probs = torch.empty((n_img * NH, S), dtype=torch.float32, device=dev)  # lse
             attn_fwd(q, k, v, out, None, rows=S, Sk=S, HD=HD, H=1, batch=n_img * NH, batch_inner=NH, ldq=E, ldk=E, ldv=E, ldo=E,
                      sQ=(S * E, HD), sK=(S * E, HD), sV=(S * E, HD), sO=(S * E, HD), scale=scale, lse=probs)

@@ -960,6 +960,30 @@ def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
         assert rel_err(got.view(n, S, NH, HD).transpose(1, 2), ref) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("n", [3, 9])
+def test_siglip_attention_forward_dedicated_kernel(ops, n):
+    """kai0_siglip_attn_fwd at the real tower's shape (256 tokens, 16 heads x 72): n = 3 runs the four-blocks-per-head form (B = 1
+    inference), n = 9 the head-per-block form (training); q / k / v as column slices of one stacked buffer.  Against the reference's
+    choreography in torch (bf16 logits, f32 softmax, bf16 P) and the log-sum-exp the recompute backward consumes."""
+    S, NH, HD = 256, 16, 72
+    E = NH * HD
+    qkv = rnd(n * S, 3 * E, seed=5, scale=0.7)
+    q, k, v = qkv[:, :E], qkv[:, E : 2 * E], qkv[:, 2 * E :]
+    out = torch.empty(n * S, E, dtype=BF16, device=dev())
+    lse = torch.empty(n * NH, S, dtype=torch.float32, device=dev())
+    ops.siglip_attn_fwd(q, k, v, out, n_img=n, S=S, NH=NH, HD=HD, ld_qkv=3 * E, ld_out=E, lse=lse)
+    Q, K, V = (t.float().reshape(n, S, NH, HD).transpose(1, 2) for t in (q, k, v))
+    logits = ((Q @ K.transpose(-1, -2)).to(BF16).float() * HD**-0.5).to(BF16).float()
+    ref = (torch.softmax(logits, -1).to(BF16).float() @ V).transpose(1, 2).reshape(n * S, E)
+    assert rel_err(out, ref) < 3e-3
+    assert (lse.view(n, NH, S) - torch.logsumexp(logits, -1)).abs().max() < 2e-2
+    # the general kernel (kai0_attn_fwd) on the same operands
+    out2 = torch.empty_like(out)
+    ops.attn_fwd(q, k, v, out2, None, rows=S, Sk=S, HD=HD, H=1, batch=n * NH, batch_inner=NH, ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E,
+                 sQ=(S * 3 * E, HD), sK=(S * 3 * E, HD), sV=(S * 3 * E, HD), sO=(S * E, HD), scale=HD**-0.5)
+    assert rel_err(out, out2) < 4e-3
+
+
 # ------------------------------------------------------------------------------- in-block skinny GEMMs (split_k = -1)
 @pytest.mark.parametrize("M,K,N", [(50, 2048, 1024), (50, 4096, 1024), (100, 4096, 1024), (50, 1024, 1024), (7, 2048, 128)])
 def test_skinny_inblock_plain_gate_residual(ops, M, K, N):
