@@ -167,26 +167,42 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         }
     };
 
-    // S^T tile of this wave: [64 keys][32 queries] = 4 x 2 MFMA tiles; A = K rows (LDS), B = Q (registers)
-    auto logits = [&](const char* tk, f32x4 (&s)[4][QT]) {
+    // S^T tile of this wave: [64 keys][16 QT queries] = 4 x QT MFMA tiles; A = K rows (LDS), B = Q (registers).
+    // Fragment reads and MFMAs are issued in BATCHES with the reads one batch ahead (double-buffered kf): left to itself hipcc
+    // schedules every ds_read right in front of the MFMA that consumes it and waits for it there (read, s_waitcnt, mfma — 64 times per
+    // tile, each one exposing the LDS latency: the listing of round 3's kernels shows exactly that, and it is why their phases "added
+    // up").  The sched_barriers pin the order; the compiler's own counted lgkmcnt then waits only for the older batch.
+    // `fill(ks)` is called inside MFMA batch ks: independent VALU work the scheduler may interleave with the batch's MFMAs.
+    auto logits_f = [&](const char* tk, f32x4 (&s)[4][QT], auto&& fill) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < QT; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+        bf16x8 kf[2][4];
+        auto rd = [&](int ks, bf16x8 (&dst)[4]) {
             const char* sub = tk + (ks >> 1) * 8192;
             const int chunk = (ks & 1) * 4 + g;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int row = mt * 16 + l15;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sub + row * 128 + ((chunk ^ (row & 7)) << 4));
+                dst[mt] = *reinterpret_cast<const bf16x8*>(sub + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+        };
+        rd(0, kf[0]);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + 1 < KSTEPS) rd(ks + 1, kf[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < QT; ++nt)
-                    s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[nt][ks], s[mt][nt], 0, 0, 0);
-            }
+                    s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][mt], qf[nt][ks], s[mt][nt], 0, 0, 0);
+            fill(ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto logits = [&](const char* tk, f32x4 (&s)[4][QT]) { logits_f(tk, s, [](int) {}); };
     // logits with the reference's rounding, masked: element (mt, nt, r) is key kt*64 + mt*16 + 4g + r, query column l15
     // key codes of tile kt for this lane's 16 keys (mt*16 + 4g + r): loaded BEFORE the tile's MFMAs so that the global
     // latency hides behind them (inside finish_logits they cost one exposed load latency per tile and pass)
@@ -279,27 +295,44 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         }
     };
     // O^T += V^T P^T : contraction over the 64 keys in two 32-key steps; step kk uses key blocks 2kk and 2kk+1, lane
-    // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.
+    // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.  Batched like the logits: the transpose
+    // reads of four output d-tiles (8 ds_read_b64_tr_b16) run one batch ahead of the MFMAs that consume them.
     auto pv_tile = [&](const char* tv, const bf16x4 (&pb)[4][QT]) {
-#pragma unroll
-        for (int kk = 0; kk < ((p.ablate & 4) ? 0 : 2); ++kk) {
-            bf16x8 pf[QT];
-#pragma unroll
-            for (int nt = 0; nt < QT; ++nt) pf[nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
+        if (p.ablate & 4) return;
+        constexpr int NB = OMT / 4;              // batches per 32-key step
+        bf16x8 vf[2][4];
+        auto rdv = [&](int b, bf16x8 (&dst)[4]) {
+            const int kk = b / NB, m0 = (b % NB) * 4;
             const int r_lo = kk * 32 + 4 * g + (l15 >> 2);   // key row this lane addresses for the transpose read
             const int r_hi = r_lo + 16;
 #pragma unroll
-            for (int mt = 0; mt < OMT; ++mt) {
-                const int chunk = mt * 2 + ((l15 & 3) >> 1);
+            for (int i = 0; i < 4; ++i) {
+                const int chunk = (m0 + i) * 2 + ((l15 & 3) >> 1);
                 const int sub = (l15 & 1) * 8;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                     (LDS_PTR(bf16x4))(tv + r_lo * V_ROWB + ((chunk ^ ((r_lo & 7) << 1)) << 4) + sub));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                     (LDS_PTR(bf16x4))(tv + r_hi * V_ROWB + ((chunk ^ ((r_hi & 7) << 1)) << 4) + sub));
-                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int nt = 0; nt < QT; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt], o[mt][nt], 0, 0, 0);
+                dst[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+        };
+        bf16x8 pf[2][QT];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt) pf[kk][nt] = __builtin_shufflevector(pb[2 * kk][nt], pb[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7);
+        rdv(0, vf[0]);
+#pragma unroll
+        for (int b = 0; b < 2 * NB; ++b) {
+            if (b + 1 < 2 * NB) rdv(b + 1, vf[(b + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kk = b / NB, m0 = (b % NB) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < QT; ++nt)
+                    o[m0 + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[b & 1][i], pf[kk][nt], o[m0 + i][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto emit_tile = [&](int kt, const char* tv, f32x4 (&s)[4][QT], const float (&m_run)[QT], const float (&inv_l)[QT]) {
@@ -376,11 +409,17 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         lds_barrier();
         for (int kt = 0; kt < ntiles; ++kt) {
             const int buf = NST == 2 ? (kt & 1) : 0;
-            if (NST == 2 && kt + 1 < ntiles) stage(kt + 1, buf ^ 1, true);
+            if (NST == 2 && kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, true);
             const char* tk = smem + buf * STAGE;
             int kc[4][4];
             load_kcodes(kt, kc);
             f32x4 s[4][QT];
+            if (p.ablate & 16) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < QT; ++nt) s[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else
             logits(tk, s);
             finish_logits(kt, s, kc);
             bf16x4 pb[4][QT];
@@ -401,7 +440,7 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = live ? __expf(s[mt][nt][r] - mn) : 0.f;    // masked: exp(-inf) = 0
+                        const float e = (p.ablate & 32) ? s[mt][nt][r] : live ? __expf(s[mt][nt][r] - mn) : 0.f;    // masked: exp(-inf) = 0
                         lsum += e;
                         pb[mt][nt][r] = f2bf(e);
                     }
@@ -621,6 +660,11 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
         else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
         else KAI0_ATTN_LAUNCH(2, 128, 1, 0, 128);
     } else {
+        // (Measured and rejected, round 4: the logits of tile kt + 1 computed ahead of the softmax of tile kt, K staged one tile ahead
+        // of V — 0.536 against 0.526 ms; the same with the two waves of a SIMD walking the phases in different orders spilled 62
+        // registers at HD = 256: 1.0-1.5 ms.  KAI0_ATTN_ABLATE on this loop: Q K^T 0.11, P V 0.11, LDS-DMA issue 0.10, everything else
+        // — mask / rounding / max / exp VALU, two cross-lane shuffles, barrier, prologue and the row-per-lane O stores — 0.24 of the
+        // 0.53 ms, serial per wave.)
         if (online && qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, -1, 128);
         else if (online) KAI0_ATTN_LAUNCH(4, 256, 1, -1, 128);
         else if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, 128);

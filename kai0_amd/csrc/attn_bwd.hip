@@ -26,6 +26,7 @@
 #include "../../include/kai0hip.h"
 #include <limits.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -208,32 +209,50 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
         const char* tk = tv + VT_BYTES;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            // dP^T = V dO^T (and, RC, S^T = K Q^T for the same (key, row) pairs): per 32-wide contraction step two V rows (two K rows)
+            // of the permuted 32-key group against the row's dO (Q) fragment.  Reads run one step ahead of the MFMAs that consume them
+            // (double-buffered; the sched_barriers pin that order — hipcc otherwise waits for every read right in front of its MFMA).
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            const int r0 = hh * 32 + arow, r1 = r0 + 4;
+            const int key0 = ((r0 & 3) | (((r0 >> 3) & 1) << 2)) << 1, key1 = ((r1 & 3) | (((r1 >> 3) & 1) << 2)) << 1;
+            // two products, one after the other (not interleaved: two fragment double-buffers at once do not fit the 256 registers
+            // of the HD = 256 recompute form): which = 0 -> V rows against dO (a0, a1), which = 1 -> K rows against Q (s0, s1)
+            auto product = [&](auto whichc, f32x4& c0, f32x4& c1, const bf16x8 (&bfr)[KSTEPS]) {
+                constexpr int which = decltype(whichc)::value;
+                bf16x8 fr[2][2];
+                auto rd = [&](int ks, bf16x8 (&dst)[2]) {
+                    if constexpr (which == 0) {
+                        const char* sub = tv + (ks >> 1) * 8192;
+                        const int chunk = (ks & 1) * 4 + g;
+                        dst[0] = *reinterpret_cast<const bf16x8*>(sub + r0 * 128 + ((chunk ^ (r0 & 7)) << 4));
+                        dst[1] = *reinterpret_cast<const bf16x8*>(sub + r1 * 128 + ((chunk ^ (r1 & 7)) << 4));
+                    } else {  // K rows: b128 reads of the row-major image (conflict-free with the key swizzle, see the header)
+                        const int kch = ks * 4 + g;
+                        dst[0] = *reinterpret_cast<const bf16x8*>(tk + r0 * K_ROWB + ((kch ^ key0) << 4));
+                        dst[1] = *reinterpret_cast<const bf16x8*>(tk + r1 * K_ROWB + ((kch ^ key1) << 4));
+                    }
+                };
+                rd(0, fr[0]);
+                rd(1, fr[1]);
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const char* sub = tv + (ks >> 1) * 8192;
-                const int chunk = (ks & 1) * 4 + g;
-                const int r0 = hh * 32 + arow, r1 = r0 + 4;
-                const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sub + r0 * 128 + ((chunk ^ (r0 & 7)) << 4));
-                const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sub + r1 * 128 + ((chunk ^ (r1 & 7)) << 4));
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[ks], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[ks], a1, 0, 0, 0);
-            }
-            // lane (row, g) holds dP for keys 64 kt + 32 hh + 8 g + e  (e < 4: a0, e >= 4: a1)
+                for (int ks = 0; ks < KSTEPS; ks += 2) {  // two steps (four reads) ahead
+                    __builtin_amdgcn_sched_barrier(0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][0], bfr[ks], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0][1], bfr[ks], c1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 2 < KSTEPS) rd(ks + 2, fr[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][0], bfr[ks + 1], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[1][1], bfr[ks + 1], c1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 3 < KSTEPS) rd(ks + 3, fr[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (RC) product(std::integral_constant<int, 1>{}, s0, s1, qf);
+            // lane (row, g) holds dP (and S) for keys 64 kt + 32 hh + 8 g + e  (e < 4: a0 / s0, e >= 4: a1 / s1)
             bf16x8 pv;
             if constexpr (RC) {
-                // S^T for the same (key, row) pairs: A = K rows (b128 reads of the row-major image), B = Q fragments
-                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-                const int r0 = hh * 32 + arow, r1 = r0 + 4;
-                const int key0 = ((r0 & 3) | (((r0 >> 3) & 1) << 2)) << 1, key1 = ((r1 & 3) | (((r1 >> 3) & 1) << 2)) << 1;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int chunk = ks * 4 + g;
-                    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tk + r0 * K_ROWB + ((chunk ^ key0) << 4));
-                    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(tk + r1 * K_ROWB + ((chunk ^ key1) << 4));
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[ks], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[ks], s1, 0, 0, 0);
-                }
                 const int kbase = kt * 64 + hh * 32 + 8 * g;
                 const i32x4 c0 = *reinterpret_cast<const i32x4*>(kc_lds + kbase), c1 = *reinterpret_cast<const i32x4*>(kc_lds + kbase + 4);
 #pragma unroll
@@ -249,25 +268,39 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
                 const u32x4 pw = pc[hh];
                 __builtin_memcpy(&pv, &pw, 16);
             }
+            product(std::integral_constant<int, 0>{}, a0, a1, dof);
             bf16x8 ds;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ds[e] = f2bf((bf2f(pv[e]) * ((e < 4 ? a0[e] : a1[e - 4]) - dsum)) * p.scale);
             u32x4 dw;
             __builtin_memcpy(&dw, &ds, 16);
             __builtin_amdgcn_raw_buffer_store_b128(dw, ds_rsrc, (int)p_off(kt, hh), 0, 0);  // always issued (OOB = dropped)
-            // dQ^T += K^T dS^T : A = K^T fragment [16 d x 32 keys] through the transpose read of the row-major K tile
+            // dQ^T += K^T dS^T : A = K^T fragment [16 d x 32 keys] through the transpose read of the row-major K tile, four d-tiles
+            // (8 transpose reads) one batch ahead of their MFMAs
             const int r_lo = hh * 32 + 8 * g + (l15 >> 2), r_hi = r_lo + 4;
             const int kkey = ((r_lo & 3) | (((r_lo >> 3) & 1) << 2)) << 1;  // same for r_hi
+            constexpr int QB = (RC && NKS == 4) ? 2 : 4;  // d-tiles per batch (the recompute form at HD = 256 is at the register limit)
+            bf16x8 kq[2][QB];
+            auto rdq = [&](int b, bf16x8 (&dst)[QB]) {
 #pragma unroll
-            for (int dt = 0; dt < ODT; ++dt) {
-                const int chunk = dt * 2 + ((l15 & 3) >> 1);
-                const int sub8 = (l15 & 1) * 8;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (LDS_PTR(bf16x4))(tk + r_lo * K_ROWB + ((chunk ^ kkey) << 4) + sub8));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (LDS_PTR(bf16x4))(tk + r_hi * K_ROWB + ((chunk ^ kkey) << 4) + sub8));
-                const bf16x8 kf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                accq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ds, accq[dt], 0, 0, 0);
+                for (int i = 0; i < QB; ++i) {
+                    const int chunk = (b * QB + i) * 2 + ((l15 & 3) >> 1);
+                    const int sub8 = (l15 & 1) * 8;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (LDS_PTR(bf16x4))(tk + r_lo * K_ROWB + ((chunk ^ kkey) << 4) + sub8));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (LDS_PTR(bf16x4))(tk + r_hi * K_ROWB + ((chunk ^ kkey) << 4) + sub8));
+                    dst[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            rdq(0, kq[0]);
+#pragma unroll
+            for (int b = 0; b < ODT / QB; ++b) {
+                if (b + 1 < ODT / QB) rdq(b + 1, kq[(b + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < QB; ++i) accq[b * QB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[b & 1][i], ds, accq[b * QB + i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // the next tile's DMA and P loads must have landed; the two dS (RC: + two P) stores issued after them may still fly
