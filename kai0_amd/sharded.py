@@ -78,15 +78,20 @@ class HipShardOps:
 class _Bucket:
     """Flat buffers of the same-dtype parameters of a run of consecutive units."""
 
+    @staticmethod
+    def layout(params, world: int, align: int = 256):
+        """(offsets, padded numel) of the flat buffer: every parameter 16-B aligned, the total a multiple of world * align elements
+        (so every rank's shard is a whole number of 256-element kernel blocks).  Pure shape arithmetic: works on meta tensors."""
+        offsets, off = [], 0
+        for p in params:
+            offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8
+        unit = world * align
+        return offsets, (off + unit - 1) // unit * unit
+
     def __init__(self, params, names, dtype, world, rank, device, *, alias_shard: bool, fsdp: bool, align=256):
         self.params, self.names, self.dtype = params, names, dtype
-        self.offsets = []
-        off = 0
-        for p in params:
-            self.offsets.append(off)
-            off += (p.numel() + 7) // 8 * 8  # keep every parameter 16-B aligned inside the flat buffer
-        unit = world * align
-        self.numel = (off + unit - 1) // unit * unit
+        self.offsets, self.numel = self.layout(params, world, align)
         self.shard = self.numel // world
         self.lo = rank * self.shard
         self.flat_param = torch.zeros(self.numel, dtype=dtype, device=device)
@@ -152,6 +157,50 @@ class _BackwardMark(torch.autograd.Function):
         return (None, None, *grads)
 
 
+def group_units(ulist, bucket_bytes: int):
+    """Consecutive units (forward-use order; a unit is never split) packed into groups of >= bucket_bytes: [(unit names, params)]."""
+    groups, cur, cur_units, cur_bytes = [], [], [], 0
+    for uname, ps in ulist:
+        cur += ps
+        cur_units.append(uname)
+        cur_bytes += sum(p.numel() * p.element_size() for p in ps)
+        if cur_bytes >= bucket_bytes:
+            groups.append((cur_units, cur))
+            cur, cur_units, cur_bytes = [], [], 0
+    if cur:
+        groups.append((cur_units, cur))
+    return groups
+
+
+def plan_partition(units, *, world_size: int, bucket_bytes: int, exclude=()):
+    """The unit -> group -> bucket partition the engine WOULD build, from shapes alone (meta tensors are fine): what is gathered /
+    reduce-scattered together, how many bytes, and what each rank keeps.  `units` as `model.sharding_units()` returns them.
+    Returns [{units, buckets: [{dtype, numel, shard, bytes, n_params}]}] plus totals — tests/test_sharded_cpu.py checks the real
+    pi0.5 model's plan at world 8 against SURVEY.md section 8e with it, and bench.py prints it into the `comm` object."""
+    skip = {id(p) for p in exclude}
+    seen, ulist = set(), []
+    for uname, ups in units:
+        ps = [p for p in ups if id(p) not in seen and id(p) not in skip and p.requires_grad]
+        seen.update(id(p) for p in ps)
+        if ps:
+            ulist.append((uname, ps))
+    plan = []
+    for unames, ps in group_units(ulist, bucket_bytes):
+        bk = []
+        for dtype in (BF16, F32):
+            dps = [p for p in ps if p.dtype == dtype]
+            if dps:
+                _, numel = _Bucket.layout(dps, world_size)
+                esz = 2 if dtype == BF16 else 4
+                bk.append({"dtype": str(dtype).replace("torch.", ""), "numel": numel, "shard": numel // world_size, "bytes": numel * esz,
+                           "n_params": len(dps)})
+        plan.append({"units": list(unames), "buckets": bk})
+    total = sum(b["bytes"] for g in plan for b in g["buckets"])
+    return {"groups": plan, "total_bytes": total, "world_size": world_size,
+            # per rank and step over the links: zero2 = reduce-scatter + all-gather, fsdp = + the backward's second all-gather
+            "bytes_per_rank_per_step": {"zero2": 2 * (world_size - 1) / world_size * total, "fsdp": 3 * (world_size - 1) / world_size * total}}
+
+
 class ShardedDataParallel:
     def __init__(self, params, *, world_size: int, rank: int, group=None, ops=None, betas=(0.9, 0.95), eps=1e-8,
                  weight_decay=1e-10, max_grad_norm=1.0, bucket_bytes: int = 512 << 20, units=None, mode: str = "zero2",
@@ -204,12 +253,7 @@ class ShardedDataParallel:
         self.groups: list[list[int]] = []  # group g -> bucket indices (one per dtype present)
         self.unit_group: dict[str, int] = {}
         self._group_last_unit: list[str] = []
-        cur, cur_bytes, cur_units = [], 0, []
-
-        def close():
-            nonlocal cur, cur_bytes, cur_units
-            if not cur:
-                return
+        for cur_units, cur in group_units(ulist, bucket_bytes):
             g = len(self.groups)
             ids = []
             for dtype in (BF16, F32):
@@ -222,15 +266,6 @@ class ShardedDataParallel:
             for u in cur_units:
                 self.unit_group[u] = g
             self._group_last_unit.append(cur_units[-1])
-            cur, cur_bytes, cur_units = [], 0, []
-
-        for uname, ps in ulist:
-            cur += ps
-            cur_units.append(uname)
-            cur_bytes += sum(p.numel() * p.element_size() for p in ps)
-            if cur_bytes >= bucket_bytes:
-                close()
-        close()
 
         self._where = {}
         for bi, b in enumerate(self.buckets):

@@ -21,7 +21,11 @@ import os
 import shutil
 import time
 
-import torch
+# RCCL on this driver needs dmabuf IPC (hipIpcGetMemHandle fails otherwise): in the environment before HIP initialises, whoever
+# launches the trainer (torchrun -m kai0_amd.train, bench.py, a notebook)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 from .optim import lr_schedule
 from .sharded import ShardedDataParallel

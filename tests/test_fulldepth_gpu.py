@@ -8,8 +8,11 @@ tokens with padding, 50 x 32 actions (S = 1018, P = 968), B = 1, identical weigh
   * every parameter gradient of mean(loss) vs ONE fp32 oracle backward.
 
 Tolerances: loss rel-L2 <= 1e-2; chunk rel-L2 <= 3e-3 and max|d| <= 2e-2 vs the bf16 oracle, rel-L2 <= 1e-2 vs
-the fp32 oracle; gradients rel-L2 <= 5e-2 vs fp32 autograd.  The measured numbers are written to gpurun_out/parity_r03.txt
-(committed as profiles/parity_r03.txt).  Host cost on the 64-core bench box: fp32 forward + backward ~25 s, fp32 chunk ~12 s."""
+the fp32 oracle.  Gradients (round 4): BASELINE.md states no tolerance, so the bar is what the REFERENCE'S OWN bf16 choreography
+loses against fp32 — the bf16 oracle is run backward too and, per parameter, HIP-vs-fp32 must stay within 1.5 x (bf16-oracle-vs-fp32)
++ 2e-3 (and under the flat 5e-2 of the earlier rounds); both columns are written out.  The measured numbers go to
+gpurun_out/parity_r04.txt (committed as profiles/parity_r04.txt) and gpurun_out/grad_table_fulldepth.txt.  Host cost on the 64-core
+bench box: fp32 forward + backward ~25 s, bf16 forward + backward ~10 s, fp32 chunk ~12 s."""
 
 import os
 import sys
@@ -24,7 +27,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 F32 = torch.float32
-REPORT = os.path.join("gpurun_out", "parity_r03.txt")
+REPORT = os.path.join("gpurun_out", "parity_r04.txt")
 WITH_BF16_ORACLE = os.environ.get("KAI0_FULLDEPTH_BF16", "1") != "0"
 
 
@@ -90,12 +93,16 @@ def test_fulldepth_loss_and_gradients_match_oracle(fd):
     r32 = rel(loss, ref32)
     line = f"loss tensor [1,50,32]: rel-L2 {r32:.3e} vs fp32 oracle (oracle fwd+bwd {t32:.1f} s)"
     rbf = None
+    gbf = {}
     if fd["obf"] is not None:
         t0 = time.time()
-        with torch.no_grad():
-            refbf = fd["obf"](fd["obs"], fd["actions"], fd["noise"], fd["time"])
+        obf = fd["obf"]
+        obf.zero_grad(set_to_none=True)
+        refbf = obf(fd["obs"], fd["actions"], fd["noise"], fd["time"])
+        refbf.mean().backward()  # the reference's own choreography through autograd: what IT loses against fp32, per parameter
+        gbf = {n: p.grad for n, p in obf.named_parameters() if p.grad is not None}
         rbf = rel(loss, refbf)
-        line += f"; {rbf:.3e} vs bf16 oracle ({time.time() - t0:.1f} s); bf16 oracle vs fp32 oracle {rel(refbf, ref32):.3e}"
+        line += f"; {rbf:.3e} vs bf16 oracle (fwd+bwd {time.time() - t0:.1f} s); bf16 oracle vs fp32 oracle {rel(refbf, ref32):.3e}"
     _report(line)
     assert loss.shape == (1, 50, 32) and loss.dtype == F32
     assert r32 <= 1e-2 and (rbf is None or rbf <= 1e-2)
@@ -112,17 +119,28 @@ def test_fulldepth_loss_and_gradients_match_oracle(fd):
             assert float(gm[n].float().norm()) < 1e-5, n
             continue
         r = rel(gm[n], g)
-        table.append((r, n, float(g.norm())))
-        if r > 5e-2:
-            bad.append((r, n))
+        rb = rel(gbf[n], g) if n in gbf else float("nan")
+        table.append((r, n, float(g.norm()), rb))
+        if r > 5e-2 or (rb == rb and r > 1.5 * rb + 2e-3):
+            bad.append((r, rb, n))
     table.sort(reverse=True)
+    with_bf = [t for t in table if t[3] == t[3]]
     _report(f"gradients of mean(loss): {len(table)} parameters vs fp32 oracle autograd, worst rel-L2 {table[0][0]:.3e} ({table[0][1]}), "
             f"median {table[len(table) // 2][0]:.3e}")  # fmt: skip
-    for r, n, gn in table[:12]:
-        _report(f"    {r:.3e}  |g|={gn:.3e}  {n}")
+    if with_bf:
+        worst_ratio = max(with_bf, key=lambda t: t[0] / (1.5 * t[3] + 2e-3))
+        _report(f"    the reference's bf16 choreography (bf16 oracle backward) vs the same fp32 gradients: worst {max(t[3] for t in with_bf):.3e}, "
+                f"median {sorted(t[3] for t in with_bf)[len(with_bf) // 2]:.3e}; HIP / (1.5 x bf16-oracle + 2e-3) at most "
+                f"{worst_ratio[0] / (1.5 * worst_ratio[3] + 2e-3):.2f} ({worst_ratio[1]}: HIP {worst_ratio[0]:.3e}, bf16 oracle {worst_ratio[3]:.3e})")  # fmt: skip
+    _report("    HIP vs fp32 | bf16 oracle vs fp32 | |g| | parameter")
+    for r, n, gn, rb in table[:12]:
+        _report(f"    {r:.3e}  {rb:.3e}  |g|={gn:.3e}  {n}")
     with open(os.path.join("gpurun_out", "grad_table_fulldepth.txt"), "w") as f:
-        for r, n, gn in table:
-            f.write(f"{r:.3e}  |g|={gn:.3e}  {n}\n")
+        f.write("# rel-L2 of d mean(loss) / d parameter against ONE fp32 oracle backward: HIP | bf16-choreography oracle | |g| | name\n")
+        for r, n, gn, rb in table:
+            f.write(f"{r:.3e}  {rb:.3e}  |g|={gn:.3e}  {n}\n")
+    if fd["obf"] is not None:
+        fd["obf"].zero_grad(set_to_none=True)
     o32.zero_grad(set_to_none=True)
     m.zero_grad(set_to_none=True)
     assert not bad, f"{len(bad)} gradient mismatches, worst: {sorted(bad, reverse=True)[:5]}"
@@ -156,3 +174,70 @@ def test_fulldepth_action_chunk_matches_oracle(fd):
         assert torch.equal(out, m.sample_actions(d, fd["gobs"], noise=fd["noise"].to(d), num_steps=10))  # replay is deterministic
     finally:
         m.train()
+
+
+def test_fulldepth_advantage_estimator_matches_oracle(fd):
+    """The Stage-Advantage estimator (pi0_pytorch.py:464-644) at full depth and width against the fp32 oracle, B = 1: six images (two
+    timesteps x three cameras: prefix 6 x 256 + 200 = 1736 tokens, the longest attention shape of the path), the trunk weights of
+    the pi0.5 fixture + a seeded value head; the weighted loss row [1, 50], its value term, and sample_values.  Tolerance: the loss
+    bar of BASELINE.md section 4 (rel-L2 <= 1e-2); the value (a tanh output in [-1, 1]) to 2e-2 absolute."""
+    import gc
+
+    from fulldepth import host_state
+    from kai0_amd.config import AdvantageEstimatorConfig
+    from kai0_amd.model import AdvantageEstimator
+    from oracle import pi0_oracle as O
+
+    dev, base = fd["dev"], fd["model"]
+    with torch.device(dev):
+        m = AdvantageEstimator(AdvantageEstimatorConfig(vocab_size=2048, loss_value_weight=0.7, loss_action_weight=1.3))
+    g = torch.Generator(device=dev).manual_seed(11)
+    with torch.no_grad():
+        m.load_state_dict(base.state_dict(), strict=False)
+        for k, p in m.named_parameters():
+            if k.startswith("value_head."):
+                p.copy_(torch.randn(p.shape, generator=g, device=dev) * (0.05 if p.dim() == 2 else 0.02))
+    m.train_augmentation = False
+    state = host_state(m)
+    cfg = O.OracleConfig(dtype="float32", vocab_size=2048)
+    with torch.device("meta"):
+        est = O.OracleAdvantageEstimator(cfg, loss_value_weight=0.7, loss_action_weight=1.3)
+    est.to_empty(device="cpu")
+    with torch.no_grad():
+        est.load_state_dict(state, strict=True)
+        for mod in est.modules():
+            if isinstance(getattr(mod, "inv_freq", None), torch.Tensor):
+                mod.inv_freq = O.rope_inv_freq(mod.inv_freq.numel() * 2).to(torch.bfloat16).float()
+            if isinstance(mod, O.SiglipVisionEmbeddings):
+                mod.position_ids = torch.arange(mod.num_patches).expand((1, -1))
+    del state
+    obs = fd["obs"]
+    gen = torch.Generator().manual_seed(12)
+    images = dict(obs.images)
+    for name in ("base_-1_rgb", "left_wrist_-1_rgb", "right_wrist_-1_rgb"):
+        images[name] = torch.rand(1, 3, 224, 224, generator=gen) * 2 - 1
+    obs6 = O.SimpleObs(images=images, image_masks={k: torch.ones(1, dtype=torch.bool) for k in images}, state=obs.state,
+                       tokenized_prompt=obs.tokenized_prompt, tokenized_prompt_mask=obs.tokenized_prompt_mask, token_ar_mask=None,
+                       token_loss_mask=None, progress=torch.tensor([0.4]))  # fmt: skip
+    from tiny import obs_to
+
+    gobs = obs_to(obs6, dev)
+    gobs.progress = obs6.progress.to(dev)
+    m.train()
+    loss, aux = m(gobs, fd["actions"].to(dev), noise=fd["noise"].to(dev), time=fd["time"].to(dev), return_loss_dict=True)
+    m.eval()
+    val = m.sample_values(dev, gobs, noise=fd["noise"].to(dev), time=fd["time"].to(dev))
+    t0 = time.time()
+    with torch.no_grad():
+        ref, raux = est(obs6, fd["actions"], fd["noise"], fd["time"], return_loss_dict=True)
+        rval = est.sample_values(obs6, fd["noise"], fd["time"])
+    r = rel(loss, ref)
+    dv = float((val.cpu() - rval).abs().max())
+    _report(f"AdvantageEstimator (six images, S = 1786): loss row [1,50] rel-L2 {r:.3e} vs fp32 oracle; value-loss term {float(aux['loss_value']):.5f} vs "
+            f"{float(raux['loss_value']):.5f}; sample_values {float(val):+.5f} vs {float(rval):+.5f} (|d| {dv:.2e}); oracle {time.time() - t0:.1f} s")  # fmt: skip
+    assert loss.shape == (1, 50) and r <= 1e-2
+    assert abs(float(aux["loss_value"]) - float(raux["loss_value"])) <= 2e-2 * max(1.0, abs(float(raux["loss_value"])))
+    assert dv <= 2e-2
+    del m, est
+    gc.collect()
+    torch.cuda.empty_cache()

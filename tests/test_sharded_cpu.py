@@ -490,3 +490,73 @@ def test_checkpoint_helpers_roundtrip_with_flat_buffers(tmp_path):
     save_file(broken, str(tmp_path / "broken.safetensors"))
     with pytest.raises(RuntimeError, match="missing"):
         load_model_safetensors(model2, str(tmp_path / "broken.safetensors"))
+
+
+# ------------------------------------------------------------------------------------------------ the REAL model's partition
+def test_real_pi05_partition_plan_at_world_8_is_the_one_of_survey_8e():
+    """The unit / bucket plan of the full-size pi0.5 model (built on the meta device: shapes only) at world 8, both modes, against
+    SURVEY.md section 8e: 27 SigLIP layer units, one unit per joint Gemma-2B + expert layer, the embedding / heads unit, the dead
+    `gemma_expert.lm_head` in none of them, every flat buffer a whole number of 256-element blocks per rank, and the bytes a rank moves
+    per step = 2 x (zero2) / 3 x (fsdp) 7/8 of the sharded bytes (sharding.py:48-102, train_pytorch.py:440-447)."""
+    from kai0_amd.config import Pi0Config
+    from kai0_amd.model import PI0Pytorch
+    from kai0_amd.sharded import plan_partition
+
+    with torch.device("meta"):
+        model = PI0Pytorch(Pi0Config())
+    model.paligemma_with_expert.to_bfloat16_for_selected_params("bfloat16")
+    units = model.sharding_units()
+    names = [u for u, _ in units]
+    assert names == ["siglip.embed"] + [f"siglip.{i}" for i in range(27)] + ["prefix"] + [f"joint.{i}" for i in range(18)] + ["head"]
+    dead = model.paligemma_with_expert.gemma_expert.lm_head.weight
+    in_units = {id(p) for _, ps in units for p in ps}
+    assert id(dead) not in in_units and dead.numel() == 257152 * 1024
+    n_used = sum(p.numel() for p in {id(p): p for _, ps in units for p in ps}.values())
+    assert n_used == sum(p.numel() for p in model.parameters()) - dead.numel() and abs(n_used - 3.353e9) < 2e6
+    per_joint = sum(p.numel() for p in dict(units)["joint.0"])
+    assert 130e6 < per_joint < 140e6 and abs(sum(p.numel() for p in dict(units)["siglip.3"]) - 15.4e6) < 0.3e6  # 110 M + 23.6 M; 15.4 M
+    W = 8
+    for mode, bucket_mb in (("fsdp", 256), ("zero2", 512)):  # the Trainer's defaults per mode
+        plan = plan_partition(units, world_size=W, bucket_bytes=bucket_mb << 20)
+        groups = plan["groups"]
+        assert [u for g in groups for u in g["units"]] == names  # forward-use order, every unit exactly once, none split
+        for g in groups:
+            for b in g["buckets"]:
+                assert b["numel"] % (W * 256) == 0 and b["shard"] * W == b["numel"]
+        total = plan["total_bytes"]
+        raw = sum(p.numel() * p.element_size() for p in {id(p): p for _, ps in units for p in ps}.values())
+        assert raw <= total < raw * 1.002 and 6.9e9 < total < 7.0e9  # 6.95 GB sharded (bf16 matrices + the f32 islands), < 0.2 % padding
+        assert plan["bytes_per_rank_per_step"][mode] == (3 if mode == "fsdp" else 2) * (W - 1) / W * total
+        if mode == "fsdp":
+            # section 8e's unit is the bucket: each joint layer alone (243 MB bf16 + 24 MB f32), the embedding unit alone
+            joint = [g for g in groups if g["units"][0].startswith("joint.")]
+            assert len(joint) == 18 and all(len(g["units"]) == 1 for g in joint)
+            assert all(abs(g["buckets"][0]["bytes"] / 2**20 - 243) < 2 and g["buckets"][1]["dtype"] == "float32" for g in joint)
+            assert [g["units"] for g in groups if "prefix" in g["units"]] == [["prefix"]]
+    # the engine itself builds exactly this partition (same helper): world 1 on a few real units of the meta model is enough to show it
+    assert plan_partition(units[:3], world_size=1, bucket_bytes=1 << 40)["groups"][0]["units"] == names[:3]
+
+
+def _worker_world8(rank, world, port, tmp, mode, rs_algo):
+    _init(rank, world, port)
+    torch.set_num_threads(1)
+    os.environ["KAI0_RS_ALGO"] = rs_algo
+    tr, model, obs, actions, noise, time = _tiny_oracle_trainer(world, rank, mode=mode)
+    assert tr.engine.mode == mode and tr.engine.rs_algo == rs_algo and tr.engine.world == 8
+    b = rank % actions.shape[0]
+    losses = [float(tr.train_step(_slice_obs(obs, b), actions[b : b + 1], noise[b : b + 1], time[b : b + 1])) for _ in range(2)]
+    tr.params_ready()
+    flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
+    box = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(box, flat)
+    assert all(torch.equal(box[0], t) for t in box)  # replicas identical after the sharded updates
+    assert all(l == l and l < 1e4 for l in losses)
+    _done(rank, tmp)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode,rs_algo", [("zero2", "rccl"), ("fsdp", "alltoall")])
+def test_tiny_trainer_at_world_8(mode, rs_algo):
+    """Eight gloo ranks (the node's size): the tiny model through Trainer.train_step in both modes / both reduce-scatter algorithms;
+    the replicas hold identical weights afterwards."""
+    _spawn(_worker_world8, 8, mode, rs_algo)
