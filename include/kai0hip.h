@@ -146,6 +146,11 @@ int kai0_gemm_desc_size(void);
 /* Diagnostics: force a tile / schedule configuration of kai0_gemm_bf16 (0 = automatic choice, the default; values as the
  * KAI0_GEMM_CFG environment variable, see gemm_bf16.hip).  Returns the previous setting.  Not thread-safe. */
 int kai0_gemm_set_cfg(int cfg);
+/* Persistent NT kernel (one resident block per CU drawing 256 x 256 tiles from an atomic, XCD-grouped ticket queue; the next tile's
+ * first half-tiles are staged before the current tile's epilogue): 0 = never, 1 = for K-contiguous one-entry GEMMs of >= 512 tiles with
+ * a fused GeGLU / GELU epilogue or K <= 2048 (default; env KAI0_GEMM_PERSIST), 2 = every eligible NT launch.  Results are bit-identical
+ * to the one-block-per-tile launches.  Returns the previous mode. */
+int kai0_gemm_set_persist(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Few-row weight-streaming GEMM for the denoise loop (B*action_horizon <= a few 64-row tiles):

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "../../include/kai0hip.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -1050,6 +1052,374 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     static_assert(MT / 4 <= 3, "extend the epilogue parts");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent NT kernel with a DYNAMIC tile queue (round 4): the quadrant schedule above, specialised for K-contiguous
+// operands, one batch entry, no split-K, with one resident block per CU that draws 256 x 256 tiles from per-XCD ticket counters until
+// none are left.  What it buys over one block per tile:
+//   * the next tile's first six half-tiles are staged (LDS-DMA) BEFORE the current tile's epilogue runs, so the K loop restarts with
+//     its pipeline full and the epilogue's operand loads / arithmetic / stores overlap with that traffic (the epilogue works out of a
+//     32 KiB slab region behind the stage buffers, in 16-row passes, instead of aliasing them);
+//   * tiles are handed out by atomic tickets, so a CU whose tile arrived cold or whose epilogue ran long simply draws later — the
+//     static assignment of round 2's experiment gave that balance up and lost inside the training step;
+//   * the ticket order is the same XCD-grouped raster as the plain launches': counter x hands out XCD x's contiguous run of the
+//     swizzled order to the blocks that (by the dispatcher's observed placement, blockIdx % 8) sit on XCD x; a block whose XCD's run
+//     is exhausted steals from the next XCD's.  Placement only affects speed, never which tile a ticket means.
+// Tickets are drawn two tiles ahead (the one needed next must be known before the current epilogue starts).  The nine counters of a
+// launch (8 queues + blocks done) live in a slot of g_ps_ctr; the last block to leave zeroes the slot, so no memset node is needed and
+// a captured graph replays correctly.
+constexpr int PS_SLOTS = 1024;
+__device__ unsigned int g_ps_ctr[PS_SLOTS][16];
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmArgs p, unsigned int* __restrict__ ctr) {
+    constexpr int TBM = 256, TBN = 256, A_TILE = TBM * BK * 2, STAGE = 2 * A_TILE, GROUP = 4, MT = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wm;
+    const int l15 = lane & 15, g = lane >> 4;
+    int* mbox = reinterpret_cast<int*>(smem + 2 * STAGE);            // two ints at the start of wave 0's slab (free between epilogues)
+    float* slab = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);  // wave-private f32 [16][64]
+    const int ntile = p.tiles_m * p.tiles_n;
+    const int qq = ntile >> 3, rr = ntile & 7;
+    // one ticket = one tile id in the swizzled order, or -1 when every queue is empty (thread 0 only).  draw() issues the atomic on
+    // the block's own XCD queue and returns its raw result — consumed much later by resolve(), so its round trip hides behind the
+    // epilogue; resolve() turns it into a tile id and only when the own queue is exhausted walks the other XCDs' queues.
+    const int x0 = blockIdx.x & 7;
+    auto draw = [&]() -> unsigned { return __hip_atomic_fetch_add(ctr + x0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto resolve = [&](unsigned t) -> int {
+        for (int a = 0; a < 8; ++a) {
+            const int x = (x0 + a) & 7;
+            const int len = qq + (x < rr ? 1 : 0);
+            if (a > 0) t = __hip_atomic_fetch_add(ctr + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)t < len) return (x < rr ? x * (qq + 1) : rr * (qq + 1) + (x - rr) * qq) + (int)t;
+        }
+        return -1;
+    };
+    auto next_ticket = [&]() -> int { return resolve(draw()); };
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)OOB, 0x00020000);
+    const bool pair = p.act == 6;
+    const __amdgpu_buffer_rsrc_t b2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(pair ? p.B2 : p.B), 0, (int)OOB, 0x00020000);
+    const int kc_chunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    const int nk = (p.K + BK - 1) / BK;
+
+    // ---- per-tile staging state (see the quadrant schedule in gemm_bf16_kernel: same half-tiles, same order, same counts) ----
+    // (identity operand row maps only — the host sends remapped operands to the plain kernel — so a tile's 8 source offsets are one
+    // multiply-add each: the 64-bit row-map arithmetic of the general kernel spilled here)
+    const uint32_t lda2 = (uint32_t)p.lda * 2, ldb2 = (uint32_t)p.ldb * 2, kc2 = (uint32_t)kc_chunk * 2;
+    auto arow_fix = [](int) -> uint32_t { return 0u; };
+    int m0 = 0, n0 = 0;
+    uint32_t ha_off[4], hb_off[4];
+    int ha_lds[4], hb_lds[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 2 * wave + j, x = h * 2 + j;
+            ha_lds[x] = ((q >> 3) * 128 + h * 64 + (q & 7) * 8) * 128;
+            hb_lds[x] = ((q >> 2) * 64 + h * 32 + (q & 3) * 8) * 128;
+        }
+    auto setup = [&](int pid) {
+        const int width = GROUP * p.tiles_n;
+        const int group = pid / width, first_m = group * GROUP;
+        const int gsz = min(p.tiles_m - first_m, GROUP);
+        const int in_g = pid - group * width;
+        m0 = (first_m + in_g % gsz) * TBM;
+        n0 = (in_g / gsz) * TBN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * wave + j, x = h * 2 + j;
+                const int Ra = m0 + (q >> 3) * 128 + h * 64 + (q & 7) * 8 + (lane >> 3);
+                ha_off[x] = Ra < p.M ? (uint32_t)Ra * lda2 + kc2 + arow_fix(Ra) : OOB;
+                int Rb = n0 + (q >> 2) * 64 + h * 32 + (q & 3) * 8 + (lane >> 3);
+                bool ok = Rb < p.N;
+                if (pair) {
+                    Rb = (n0 >> 1) + (q >> 2) * 32 + (q & 3) * 8 + (lane >> 3);
+                    ok = Rb < (p.N >> 1);
+                }
+                hb_off[x] = ok ? (uint32_t)Rb * ldb2 + kc2 : OOB;
+            }
+    };
+    auto issue_half = [&](bool isb, int h, int t) {
+        const int k0 = t * BK;
+        const bool kc_in = (k0 + kc_chunk) < p.K;
+        char* base = smem + (t & 1) * STAGE + (isb ? A_TILE : 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int x = h * 2 + j;
+            const uint32_t o = isb ? hb_off[x] : ha_off[x];
+            const uint32_t off = (kc_in && o != OOB) ? o + (uint32_t)k0 * 2 : OOB;
+            glds16(isb ? ((pair && h == 1) ? b2_rsrc : b_rsrc) : a_rsrc, off, base + (isb ? hb_lds[x] : ha_lds[x]));
+        }
+    };
+    auto prologue_issue = [&]() {
+        issue_half(false, 0, 0);
+        issue_half(true, 1, 0);
+        issue_half(true, 0, 0);
+        issue_half(false, 1, 0);
+        issue_half(false, 0, 1);
+        issue_half(true, 1, 1);
+    };
+    auto frag = [&](const char* tile, int row0, int ks) -> bf16x8 {
+        const int row = row0 + l15;
+        return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4));
+    };
+
+    // ---- first two tickets --------------------------------------------------------------------------------------------------
+    if (tid == 0) {
+        const int t0 = next_ticket();
+        mbox[0] = t0;
+        mbox[1] = t0 >= 0 ? next_ticket() : -1;
+    }
+    __syncthreads();
+    int cur = mbox[0], nxt = mbox[1];
+    __syncthreads();
+    if (cur >= 0) {
+        setup(cur);
+        prologue_issue();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        lds_barrier();
+        if (grp == 1) lds_barrier();  // stagger group 1 by one slot
+    }
+    const int64_t cz = 0, rz = 0, vz = 0;
+    while (cur >= 0) {
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[4][2], bq[2][2];
+        auto read_a = [&](const char* ta, int h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = frag(ta, wm * 128 + (h * 4 + i) * 16, ks);
+        };
+        auto read_b = [&](const char* tb, int h) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bq[j][ks] = frag(tb, wn * 64 + (h * 2 + j) * 16, ks);
+        };
+        auto quad = [&](auto ahc, auto bhc) {
+            constexpr int ah = decltype(ahc)::value, bh = decltype(bhc)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bq[j][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        for (int t = 0; t < nk; ++t) {
+            const char* ta = smem + (t & 1) * STAGE;
+            const char* tb = ta + A_TILE;
+            read_b(tb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(ta, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_half(true, 0, t + 1);
+            lds_barrier();
+            quad(I0{}, I0{});
+            lds_barrier();
+            read_b(tb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_half(false, 1, t + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            lds_barrier();
+            quad(I0{}, I1{});
+            lds_barrier();
+            read_a(ta, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_half(false, 0, t + 2);
+            lds_barrier();
+            quad(I1{}, I1{});
+            lds_barrier();
+            read_b(tb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_half(true, 1, t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            lds_barrier();
+            quad(I1{}, I0{});
+            lds_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill pieces have landed: the stage buffers are free
+        if (grp == 0) lds_barrier();                      // re-align the two groups
+        lds_barrier();
+
+        // ---- hand-over: ticket for the tile after next, next tile's first half-tiles, THEN this tile's epilogue ------------------
+        const int m0c = m0, n0c = n0;
+        int nn = -1;
+        unsigned raw = 0;
+        if (tid == 0 && nxt >= 0) raw = draw();
+        if (nxt >= 0) {
+            setup(nxt);
+            prologue_issue();
+        }
+        const int ccol = n0c + wn * 64 + (lane & 7) * 8;
+        const bool col_ok = ccol < ((p.N + 7) & ~7);
+        const bool fused_fast = p.act >= 2 && p.act <= 5 && p.bias == nullptr && p.gate == nullptr && p.residual == nullptr && !p.accumulate &&
+                                !p.out_f32 && p.nseg == 0 && (p.act == 4 || p.scale == 1.0f) && (p.act != 3 || p.pre_out != nullptr);
+        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab
+            __builtin_amdgcn_wave_barrier();
+            // (static indexing of acc: callers pass compile-time ti through the unrolled loops below)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(4 * g + r) * 64 + j * 16 + l15] = acc[ti][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (pair) {
+            const int ocol = (n0c >> 1) + wn * 32 + (lane & 3) * 8;
+            const bool ocol_ok = ocol < (p.N >> 1);
+            bf16_t* cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int ti = 0; ti < MT; ++ti) {
+                to_slab(ti);
+                const int row = m0c + wm * 128 + ti * 16 + (lane >> 2);
+                const float* sp = slab + (lane >> 2) * 64 + (lane & 3) * 8;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp), g1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(sp + 32), u1 = *reinterpret_cast<const f32x4*>(sp + 36);
+                if (row < p.M && ocol_ok) {
+                    const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                    const float uv[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                    bf16x8 gb, ub, hb;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 gr = rbf2(f32x2{gv[e], gv[e + 1]}), ur = rbf2(f32x2{uv[e], uv[e + 1]});
+                        const f32x2 hv = rbf2(gelu_tanh2(gr)) * ur;
+                        gb[e] = f2bf(gr[0]); gb[e + 1] = f2bf(gr[1]);
+                        ub[e] = f2bf(ur[0]); ub[e + 1] = f2bf(ur[1]);
+                        hb[e] = f2bf(hv[0]); hb[e + 1] = f2bf(hv[1]);
+                    }
+                    const int64_t o = p.cmap(row) * p.ldc + ocol;
+                    *reinterpret_cast<bf16x8*>(cb + o) = hb;
+                    if (p.pre_out != nullptr) store_pre8(p.pre_out + o, gb, p.nt_pre);
+                    if (p.pre_out2 != nullptr) store_pre8(p.pre_out2 + o, ub, p.nt_pre);
+                }
+            }
+        } else if (fused_fast) {
+            bf16_t* cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // the extra [M][N] operands of this 64-row half requested before its accumulators go through the slab
+                bf16x8 s0[8], s1[8];
+                float ds[8];
+                const int rbase = m0c + wm * 128 + h * 64 + (lane >> 3);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = rbase + it * 8;
+                    s0[it] = bf16x8{};
+                    s1[it] = bf16x8{};
+                    ds[it] = 0.f;
+                    if (row < p.M && col_ok) {
+                        const int64_t o = p.cmap(row) * p.ldc + ccol;
+                        s0[it] = *reinterpret_cast<const bf16x8*>(p.aux1 + o);
+                        if (p.act == 3) s1[it] = *reinterpret_cast<const bf16x8*>(p.aux2 + o);
+                        if (p.act == 4) ds[it] = p.rowvec[(int64_t)row * p.rv_ld];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    to_slab(h * 4 + i);
+#pragma unroll
+                    for (int it2 = 0; it2 < 2; ++it2) {
+                        const int it = 2 * i + it2;
+                        const int row = rbase + it * 8;
+                        const float* sp = slab + (it2 * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        if (row >= p.M || !col_ok) continue;
+                        const int64_t o = p.cmap(row) * p.ldc + ccol;
+                        bf16x8 ov;
+                        if (p.act == 2) {
+                            if (p.pre_out != nullptr) {
+                                bf16x8 uv;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) uv[e] = f2bf(v[e]);
+                                *reinterpret_cast<bf16x8*>(p.pre_out + o) = uv;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                const f32x2 r = rbf2(gelu_tanh2(f32x2{bf2f(s0[it][e]), bf2f(s0[it][e + 1])})) * rbf2(f32x2{v[e], v[e + 1]});
+                                ov[e] = f2bf(r[0]);
+                                ov[e + 1] = f2bf(r[1]);
+                            }
+                        } else if (p.act == 3) {
+                            bf16x8 du;
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                const f32x2 dh = rbf2(f32x2{v[e], v[e + 1]});
+                                f32x2 gl, gr;
+                                gelu_tanh_both2(f32x2{bf2f(s0[it][e]), bf2f(s0[it][e + 1])}, gl, gr);
+                                const f32x2 a = dh * rbf2(gl);
+                                const f32x2 b = rbf2(dh * f32x2{bf2f(s1[it][e]), bf2f(s1[it][e + 1])}) * gr;
+                                du[e] = f2bf(a[0]); du[e + 1] = f2bf(a[1]);
+                                ov[e] = f2bf(b[0]); ov[e + 1] = f2bf(b[1]);
+                            }
+                            *reinterpret_cast<bf16x8*>(p.pre_out + o) = du;
+                        } else if (p.act == 5) {
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                f32x2 gl, gr;
+                                gelu_tanh_both2(f32x2{bf2f(s0[it][e]), bf2f(s0[it][e + 1])}, gl, gr);
+                                const f32x2 b = rbf2(f32x2{v[e], v[e + 1]}) * gr;
+                                ov[e] = f2bf(b[0]); ov[e + 1] = f2bf(b[1]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ov[e] = f2bf((bf2f(s0[it][e]) * (v[e] - ds[it])) * p.scale);
+                        }
+                        *reinterpret_cast<bf16x8*>(cb + o) = ov;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < MT; ++ti) {
+                to_slab(ti);
+#pragma unroll 1
+                for (int it2 = 0; it2 < 2; ++it2) {
+                    const int lr = it2 * 8 + (lane >> 3);
+                    const int row = m0c + wm * 128 + ti * 16 + lr;
+                    if (row >= p.M || !col_ok) continue;
+                    const float* sp = slab + lr * 64 + (lane & 7) * 8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    epilogue8(p, v, row, ccol, cz, rz, vz, p.C, p.out_f32 != 0);
+                }
+            }
+        }
+        // ---- next tile ------------------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) mbox[0] = nxt >= 0 ? resolve(raw) : -1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile's first half-tiles (and the epilogue's own traffic)
+        lds_barrier();
+        nn = mbox[0];
+        cur = nxt;
+        nxt = nn;
+        lds_barrier();  // everyone has read the mailbox before wave 0's slab is written again
+        if (cur >= 0 && grp == 1) lds_barrier();  // stagger group 1 by one slot
+    }
+    // ---- leave: the last block zeroes the launch's counters (the slot is then reusable by a later launch / a graph replay) ---------
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned done = __hip_atomic_fetch_add(ctr + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // split-K reduction: sum the f32 partial tiles of a (batch entry, 8-column group) and run the fused epilogue once.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int z = blockIdx.y;
@@ -1216,12 +1586,19 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
 }
 
 int g_gemm_cfg = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
+int g_gemm_persist = [] { const char* e = getenv("KAI0_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
 
 }  // namespace
 
 KAI0_API int kai0_gemm_set_cfg(int cfg) {
     const int old = g_gemm_cfg;
     g_gemm_cfg = cfg;
+    return old;
+}
+
+KAI0_API int kai0_gemm_set_persist(int mode) {
+    const int old = g_gemm_persist;
+    g_gemm_persist = mode;
     return old;
 }
 
@@ -1357,6 +1734,35 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     const bool ring = d->act != 6 && (forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc));
     // forced 8: 384x256x64 plain loop (NT / NN only): 20 % fewer staged bytes per FLOP than 256x256
     // forced 9 / 10: the quadrant schedule for NT (DMA pieces after the fragment reads / between the MFMAs), others as picked
+    // persistent NT kernel with the dynamic tile queue (KAI0_GEMM_PERSIST: 0 never, 1 = the rule below, 2 = every eligible NT launch)
+    const int persist = g_gemm_persist;
+    const bool ps_ok = !forced && persist && big && d->a_kc && d->b_kc && batch == 1 && split == 1 && big_tiles >= 512 &&
+                       (p.K % 8) == 0 && !d->rowvec && d->a_rpb == 0 && d->b_rpb == 0;
+    // the rule (measured inside the training step, tools/gpu_bd.sh): the wide MLP shapes gain — 30976 x 16384 x 2048 with the GeGLU
+    // epilogues 993 -> 1046 TFLOP/s (1056 -> 1165 for the pair GEMM alone), x 2048 x 16384 1371 -> 1385 — while launches of < ~1000
+    // tiles (q|k|v, o_proj, SigLIP) lose 1-8 %: their tiles are too few for the queue to pay for its hand-over
+    const bool ps_rule = p.N >= 8192 || d->K >= 8192;
+    if (ps_ok && (persist == 2 || ps_rule)) {
+        constexpr int LDS = 2 * 2 * 256 * 64 * 2 + 8 * 4096;  // two stages + the epilogue slabs = 160 KiB
+        static unsigned int* ctr_base = nullptr;
+        static std::atomic<unsigned> next_slot{0};
+        if (ctr_base == nullptr) {
+            void* sym = nullptr;
+            hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_ps_ctr));
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            KAI0_REQUIRE(e == hipSuccess, "kai0_gemm_bf16: persistent kernel setup failed: %s", hipGetErrorString(e));
+            ctr_base = (unsigned int*)sym;
+        }
+        p.tiles_m = (d->M + 255) / 256;
+        p.tiles_n = (p.N + 255) / 256;
+        int ncu = 256;
+        static const int cus = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
+        ncu = cus > 0 ? cus : 256;
+        const int nblk = (int)std::min<int64_t>(big_tiles, ncu);
+        unsigned int* ctr = ctr_base + (size_t)(next_slot.fetch_add(1) % PS_SLOTS) * 16;
+        hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(nblk), dim3(512), LDS, s, p, ctr);
+        return kai0_check_launch("kai0_gemm_bf16 (persistent)");
+    }
     if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
     else if (forced == 9) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
     else if (forced == 10) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);

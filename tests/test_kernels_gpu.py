@@ -960,6 +960,51 @@ def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
         assert rel_err(got.view(n, S, NH, HD).transpose(1, 2), ref) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("case", ["plain", "bias_res", "gelu_pre", "geglu_pair", "geglu_fwd", "geglu_bwd", "gelu_bwd", "ragged"])
+def test_persistent_gemm_is_bit_identical_to_one_block_per_tile(ops, case):
+    """kai0_gemm_set_persist(2): the persistent NT kernel (dynamic per-XCD tile queue, next tile staged before the epilogue, 16-row
+    epilogue slabs) against the one-block-per-tile launches on every epilogue it serves: same bits, every output (C, pre_out,
+    pre_out2), including ragged edges and more tiles than resident blocks."""
+    from kai0_amd import _lib
+
+    lib = _lib.load()
+    M, N, K = (4096, 8192, 320) if case != "ragged" else (4000, 8200, 328)
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    kw, nout = {}, 1
+    if case == "bias_res":
+        kw = dict(bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N)
+    elif case == "gelu_pre":
+        kw, nout = dict(bias=rnd(N, seed=3), act=1), 2
+    elif case == "geglu_pair":
+        kw, nout = dict(act=6, B2=rnd(N, K, seed=5, scale=0.05)), 3
+    elif case == "geglu_fwd":
+        kw, nout = dict(act=2, aux1=rnd(M, N, seed=6)), 2
+    elif case == "geglu_bwd":
+        kw, nout = dict(act=3, aux1=rnd(M, N, seed=6), aux2=rnd(M, N, seed=7)), 2
+    elif case == "gelu_bwd":
+        kw = dict(act=5, aux1=rnd(M, N, seed=6))
+    res = {}
+    try:
+        for mode in (0, 2):
+            lib.kai0_gemm_set_persist(mode)
+            outs = [torch.full((M, N), 3.0, dtype=BF16, device=dev()) for _ in range(nout)]
+            k2 = dict(kw)
+            if nout >= 2:
+                k2["pre_out"] = outs[1]
+            if nout >= 3:
+                k2["pre_out2"] = outs[2]
+            ops.gemm(A, W, outs[0], M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **k2)
+            torch.cuda.synchronize()
+            res[mode] = outs
+    finally:
+        lib.kai0_gemm_set_persist(1)
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
+    ref = A.float() @ W.float().t()  # and it is the right product (plain case: against fp32)
+    if case == "plain":
+        assert rel_err(res[2][0], ref) < 5e-3
+
+
 @pytest.mark.parametrize("n", [3, 9])
 def test_siglip_attention_forward_dedicated_kernel(ops, n):
     """kai0_siglip_attn_fwd at the real tower's shape (256 tokens, 16 heads x 72): n = 3 runs the four-blocks-per-head form (B = 1
