@@ -211,6 +211,23 @@ typedef struct kai0_skinny_desc {
     int64_t mod_ld;
     int32_t mod_rpb;
     float eps;
+    /* split_k == -1, the adaRMS norm FOLDED (round 4; inference, where the modulation is a constant of the engine: it depends on the
+     * Euler schedule's time values and the weights only, modeling_gemma.py:49-104 with cond = time MLP(t)).  With the caller passing
+     *   W' = bf16(W * (1 + scale)[k])  as W   and   cvec[n] = sum_k shift[k] * W[n][k],
+     * y = ((x * rstd) * (1 + scale) + shift) W^T = rstd * (x W'^T) + cvec: the kernel multiplies the RAW residual stream and applies
+     * the row factor and cvec to the f32 sum (modes 1, 2; K = 1024; `mod` must be NULL) — no row statistics pass over the tile and
+     * no per-element normalisation in front of the MFMAs.  rstd[row] = rsqrt(sum_p rowsq_in[p][row] / K + eps), the partial sums of
+     * squares written by the launch that produced x:
+     *   rowsq_out (mode 0, in-block): this launch's own partials of the bf16 rows it stores, [N / 16][rowsq_out_ld] f32, one per
+     *   16-column tile; kai0_denoise_glue writes one partial per row for the step's first layer.
+     * The rounding points move (the weights are rounded after the scale instead of the activations after the norm): inside the
+     * chunk tolerance of BASELINE.md section 4, not bit-identical to the `mod` form. */
+    const float* rowsq_in;
+    const float* cvec;
+    int32_t rowsq_parts, _pad2;
+    int64_t rowsq_ld;
+    float* rowsq_out;
+    int64_t rowsq_out_ld;
 } kai0_skinny_desc;
 
 int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stream);
@@ -464,10 +481,11 @@ int kai0_euler_step(float* x, const float* v, float dt, int64_t n, kai0_stream_t
  * [scale | shift | gate] of leading dimension mod_ld, one per rows_per_batch rows), v_t = action_out_proj(f32(y)) (w_out [A][D],
  * b_out [A], f32), x_t[rows][A] += dt * v_t in place — and with xs_next != NULL it OPENS the next one — xs_next[rows][D] =
  * bf16(action_in_proj(x_t)) (w_in [D][A], b_in [D], f32).  Replaces kai0_adarms_fwd + cast + kai0_gemm_f32 + kai0_euler_step +
- * kai0_gemm_f32 + cast; A <= 64, D % 8 == 0, D <= 2048. */
+ * kai0_gemm_f32 + cast; A <= 64, D % 8 == 0, D <= 2048.  rowsq_next (optional, with xs_next): f32 [rows], the sum of squares of every
+ * new bf16 row — the statistic the first layer's folded adaRMS projection consumes (kai0_skinny_desc.rowsq_in, one partial). */
 int kai0_denoise_glue(const void* xs, const float* mod, int64_t mod_ld, int rows_per_batch, float eps, const float* w_out,
                       const float* b_out, float* x_t, float dt, const float* w_in, const float* b_in, void* xs_next,
-                      int64_t rows, int D, int A, kai0_stream_t stream);
+                      int64_t rows, int D, int A, float* rowsq_next, kai0_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer (train_pytorch.py:469-475,557-561; optimizer.py:15-85).

@@ -94,6 +94,8 @@ class SkinnyDesc(C.Structure):
         ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("w_packed", C.c_int32),
         ("workspace", c_p), ("workspace_bytes", c_i64),
         ("mod", c_p), ("mod_ld", c_i64), ("mod_rpb", C.c_int32), ("eps", c_f),
+        ("rowsq_in", c_p), ("cvec", c_p), ("rowsq_parts", C.c_int32), ("_pad2", C.c_int32), ("rowsq_ld", c_i64),
+        ("rowsq_out", c_p), ("rowsq_out_ld", c_i64),
     ]  # fmt: skip
 
 
@@ -159,7 +161,7 @@ _PROTOS: dict[str, list] = {
     "kai0_mse_fwd": [c_p, c_p, c_p, c_i64, c_p],
     "kai0_mse_bwd": [c_p, c_p, c_p, c_p, c_i64, c_p],
     "kai0_euler_step": [c_p, c_p, c_f, c_i64, c_p],
-    "kai0_denoise_glue": [c_p, c_p, c_i64, c_i, c_f, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_denoise_glue": [c_p, c_p, c_i64, c_i, c_f, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p],
     "kai0_sumsq": [c_p, c_i, c_i64, c_p, c_p, c_p],
     "kai0_sum_chunks": [c_p, c_i, c_i, c_i64, c_i64, c_p, c_p],
     "kai0_clip_coef": [c_p, c_f, c_p, c_p, c_p],

@@ -294,6 +294,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    if constexpr (MT == 4) {
+        // 128 x 128 configurations (the B = 1 inference GEMMs: a launch is ~20 us, ~190 of them per action chunk): every kernel
+        // argument the prologue needs is pulled into SGPRs in ONE batch of scalar loads.  Left to itself hipcc loads each field of
+        // the by-value struct next to its first use: six serial s_load / s_waitcnt round trips stood in front of the first LDS-DMA.
+        asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb), "s"(p.tiles_m), "s"(p.tiles_n),
+                     "s"(p.split_k), "s"(p.k_chunk), "s"(p.batch_inner), "s"(p.amap.rpb), "s"(p.bmap.rpb), "s"(p.act), "s"(p.sA1),
+                     "s"(p.sB1), "s"(p.sA2), "s"(p.sB2));
+    }
     // ---- block -> tile (XCD-aware bijective remap, then grouped raster) -------------------------
     const int nwg = gridDim.x;
     int pid = blockIdx.x;
@@ -1736,7 +1744,8 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // forced 9 / 10: the quadrant schedule for NT (DMA pieces after the fragment reads / between the MFMAs), others as picked
     // persistent NT kernel with the dynamic tile queue (KAI0_GEMM_PERSIST: 0 never, 1 = the rule below, 2 = every eligible NT launch)
     const int persist = g_gemm_persist;
-    const bool ps_ok = !forced && persist && big && d->a_kc && d->b_kc && batch == 1 && split == 1 && big_tiles >= 512 &&
+    const bool ps_ok = !forced && persist && big && d->a_kc && d->b_kc && batch == 1 && split == 1 &&
+                       big_tiles >= (persist == 2 ? 512 : 2048) &&  // (B = 1 prefix MLP, 512 tiles = two per CU: 97 -> 136 us persistent)
                        (p.K % 8) == 0 && !d->rowvec && d->a_rpb == 0 && d->b_rpb == 0;
     // the rule (measured inside the training step, tools/gpu_bd.sh): the wide MLP shapes gain — 30976 x 16384 x 2048 with the GeGLU
     // epilogues 993 -> 1046 TFLOP/s (1056 -> 1165 for the pair GEMM alone), x 2048 x 16384 1371 -> 1385 — while launches of < ~1000

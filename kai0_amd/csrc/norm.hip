@@ -103,13 +103,15 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
                                                            int rpb, float eps, const float* __restrict__ w_out,
                                                            const float* __restrict__ b_out, float* __restrict__ x_t, float dt,
                                                            const float* __restrict__ w_in, const float* __restrict__ b_in,
-                                                           bf16_t* __restrict__ xs_next, int64_t rows, int D, int A) {
+                                                           bf16_t* __restrict__ xs_next, int64_t rows, int D, int A,
+                                                           float* __restrict__ rowsq_next) {
     // one block per action row; the chain is a handful of dependent memory round trips, so everything independent is in flight at
     // once: each of the four waves normalises the row itself (16 elements per lane) and takes A / 4 of the outputs of the first dot
     // with all their weight loads issued up front; the second dot gives every thread D / 256 outputs
-    __shared__ float xa_s[64], x0_s[64], bo_s[64];
+    __shared__ float xa_s[64], x0_s[64], bo_s[64], red_s[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
+    float ssn = 0.f;  // sum of squares of this thread's share of the new bf16 row (the next layer's folded adaRMS statistic)
     const int nchunk = D >> 3;
     if (tid < A) {  // requested at kernel entry, read after the dots
         x0_s[tid] = x_t[row * A + tid];
@@ -252,7 +254,13 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
             for (int q = 0; q < 8; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc += xa[4 * q + e] * w[u][q][e];
-            xs_next[row * D + tid + 256 * u] = f2bf(acc + bi[u]);
+            const bf16_t o = f2bf(acc + bi[u]);
+            xs_next[row * D + tid + 256 * u] = o;
+            ssn += bf2f(o) * bf2f(o);
+        }
+        if (rowsq_next != nullptr) {
+            const float t = block_sum<4>(ssn, red_s);
+            if (tid == 0) rowsq_next[row] = t;
         }
         return;
     }
@@ -260,7 +268,13 @@ __global__ __launch_bounds__(256) void denoise_glue_kernel(const bf16_t* __restr
         const float* wr = w_in + (int64_t)n * A;
         float acc = 0.f;
         for (int j = 0; j < A; ++j) acc += xa_s[j] * wr[j];
-        xs_next[row * D + n] = f2bf(acc + b_in[n]);
+        const bf16_t o = f2bf(acc + b_in[n]);
+        xs_next[row * D + n] = o;
+        ssn += bf2f(o) * bf2f(o);
+    }
+    if (rowsq_next != nullptr) {
+        const float t = block_sum<4>(ssn, red_s);
+        if (tid == 0) rowsq_next[row] = t;
     }
 }
 
@@ -731,14 +745,15 @@ KAI0_API int kai0_adarms_fwd(const void* x, const float* mod, void* y, void* gat
 
 KAI0_API int kai0_denoise_glue(const void* xs, const float* mod, int64_t mod_ld, int rows_per_batch, float eps, const float* w_out,
                                const float* b_out, float* x_t, float dt, const float* w_in, const float* b_in, void* xs_next,
-                               int64_t rows, int D, int A, kai0_stream_t stream) {
+                               int64_t rows, int D, int A, float* rowsq_next, kai0_stream_t stream) {
     CHECK_D("kai0_denoise_glue", D);
     KAI0_REQUIRE(x_t && A >= 1 && A <= 64 && (xs == nullptr || (mod && w_out && b_out && rows_per_batch > 0 && mod_ld >= 2 * (int64_t)D)) &&
                      (xs_next == nullptr || (w_in && b_in)) && (xs != nullptr || xs_next != nullptr),
                  "kai0_denoise_glue: bad arguments (A <= 64; closing a step needs xs, mod, w_out, b_out; opening one w_in, b_in, xs_next)");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(denoise_glue_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xs, mod,
-                       mod_ld, rows_per_batch, eps, w_out, b_out, x_t, dt, w_in, b_in, (bf16_t*)xs_next, rows, D, A);
+                       mod_ld, rows_per_batch, eps, w_out, b_out, x_t, dt, w_in, b_in, (bf16_t*)xs_next, rows, D, A,
+                       xs_next != nullptr ? rowsq_next : nullptr);
     return kai0_check_launch("kai0_denoise_glue");
 }
 

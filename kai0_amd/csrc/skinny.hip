@@ -64,6 +64,14 @@ struct SkinnyArgs {
     int64_t mod_ld;
     float eps;
     int w_packed;  // skinny2: W in fragment-major 1-KiB blocks (kai0hip.h)
+    // folded adaRMS (skinny2, kai0hip.h `rowsq_in`): the norm's scale is folded into W and its shift into cvec by the caller; the kernel
+    // multiplies raw x and applies out = acc * rstd[row] + cvec[n], rstd from the producer's per-column-tile partial sums of squares
+    const float* rowsq_in;   // [rowsq_parts][rowsq_ld] f32
+    const float* cvec;       // [N] f32
+    int rowsq_parts;
+    int64_t rowsq_ld;
+    float* rowsq_out;        // mode 0 (in-block): this launch's own partials, [N / 16][rowsq_out_ld]
+    int64_t rowsq_out_ld;
 };
 
 constexpr int TM = 64, TN = 32;
@@ -71,7 +79,8 @@ constexpr int RED_LD = TN + 1;  // f32 row stride of a wave's partial tile in LD
 
 // The fused epilogue on this thread's 4 + 4 outputs: v0 = columns n0 .. n0+3, v1 = columns n1 .. n1+3 (n1 = n0 + pair_stride; only
 // v0 when `pair` is false) of output row `mrow` (f32 sums over the whole contraction).  Rounding points: see kai0hip.h.
-__device__ __forceinline__ void sk_epilogue(const SkinnyArgs& p, float (&v0)[4], float (&v1)[4], int mrow, int n0, int n1, bool pair) {
+__device__ __forceinline__ void sk_epilogue(const SkinnyArgs& p, float (&v0)[4], float (&v1)[4], int mrow, int n0, int n1, bool pair,
+                                            int col_tile = 0) {
     const int64_t orow = p.cmap(mrow);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -163,6 +172,16 @@ __device__ __forceinline__ void sk_epilogue(const SkinnyArgs& p, float (&v0)[4],
     bf16_t* dp = p.seg[0].dst + orow * p.seg[0].ld;
     *reinterpret_cast<bf16x4*>(dp + n0) = o1;
     if (pair) *reinterpret_cast<bf16x4*>(dp + n1) = o2;
+    if (p.rowsq_out != nullptr) {
+        // sum of squares of the bf16 values just stored over this block's 16 columns of the row (the four threads tid & 3 of a row
+        // are neighbours in the wave): the consumer's adaRMS statistic, one partial per column tile, summed there in tile order
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += bf2f(o1[e]) * bf2f(o1[e]);
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        if ((threadIdx.x & 3) == 0) p.rowsq_out[(int64_t)col_tile * p.rowsq_out_ld + mrow] = ss;
+    }
 }
 
 // NW waves share the block's K range (k_blk / NW each, NC chunks of 128): 4 x 2 chunks or 8 x 1 chunk for k_blk = 1024
@@ -294,8 +313,9 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny_kernel(const SkinnyArgs p) 
 #define SK2_STAMP(i) do { (void)trace; } while (0)
 #endif
 
-template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false>
+template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p) {
+    static_assert(!(FOLD && ADA), "the folded form has no prologue");
     constexpr int TMB = 16 * MTL;
     constexpr int TN2 = PAIR ? 32 : 16;
     constexpr int LD2 = TN2 + 1;
@@ -372,6 +392,20 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
                 if constexpr (PAIR) wf[c][1][j] = *reinterpret_cast<const bf16x8*>(w1 + c * wc + j * wj);
             }
         }
+    // FOLD: the producer's partial sums of squares of this block's rows, requested here (behind the weight stream), reduced after
+    // the MFMAs: P = threads per row, each adds its share of the `rowsq_parts` partials in tile order, the P shares meet by shuffles
+    constexpr int FP = FOLD ? (NW * 64) / TMB : 1;      // threads per row (8 .. 32)
+    constexpr int FQ = FOLD ? (64 + FP - 1) / FP : 1;   // partials per thread (<= 64 column tiles)
+    float fsq[FQ];
+    if constexpr (FOLD) {
+        const int frow = min(m0 + tid / FP, m_end - 1), fj = tid % FP;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int part = fj * FQ + q;
+            const float v = p.rowsq_in[(int64_t)min(part, p.rowsq_parts - 1) * p.rowsq_ld + frow];  // clamped, not guarded
+            fsq[q] = part < p.rowsq_parts ? v : 0.f;
+        }
+    }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     f32x4 mod_piece[(ALDS && ADA) ? (2 * KB / 4 + NW * 64 - 1) / (NW * 64) : 1];
     if constexpr (ALDS && ADA) {
@@ -527,6 +561,14 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
         for (int s2 = 0; s2 < (PAIR ? 2 : 1); ++s2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][mt * 16 + 4 * g + r][s2 * 16 + i] = acc[mt][s2][r];
+    if constexpr (FOLD) {
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) ss += fsq[q];
+#pragma unroll
+        for (int off = 1; off < FP; off <<= 1) ss += __shfl_xor(ss, off, 64);
+        if (tid % FP == 0) ssq[0][tid / FP] = rsqrtf(ss / (float)p.K + p.eps);
+    }
     __syncthreads();
     SK2_STAMP(6);  // wave partials in LDS
     if (tid >= TMB * 4) return;  // TMB rows x 4 column quads finish the tile
@@ -543,8 +585,18 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
         v0[e] = s0;
         v1[e] = s1;
     }
+    if constexpr (FOLD) {  // out = (x W'^T) * rstd + c: the norm's per-row factor and the folded shift term
+        const float rstd = ssq[0][row];
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.cvec + n_sub0 + 4 * q);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.cvec + n_sub1 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = v0[e] * rstd + c0[e];
+            v1[e] = v1[e] * rstd + c1[e];
+        }
+    }
     const int mrow = m0 + row;
-    if (mrow < m_end) sk_epilogue(p, v0, v1, mrow, n_sub0 + 4 * q, n_sub1 + 4 * q, PAIR);
+    if (mrow < m_end) sk_epilogue(p, v0, v1, mrow, n_sub0 + 4 * q, n_sub1 + 4 * q, PAIR, tile);
     SK2_STAMP(7);  // epilogue stores issued
 }
 
@@ -570,7 +622,7 @@ KAI0_API int64_t kai0_skinny_workspace_bytes(int M, int N, int split_k) {
 
 namespace {
 
-template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false>
+template <int NW, int MTL, bool PAIR, bool ADA, int NC = 2, bool WNT = true, bool ALDS = false, bool FOLD = false>
 int launch_skinny2(const SkinnyArgs& a, hipStream_t s) {
     constexpr int TMB = 16 * MTL, LD2 = (PAIR ? 32 : 16) + 1;
     constexpr int RED = (int)sizeof(float) * NW * TMB * LD2, ATILE = ALDS ? TMB * (NW * NC * 128 * 2 + 16) : 0;
@@ -579,7 +631,7 @@ int launch_skinny2(const SkinnyArgs& a, hipStream_t s) {
     // ADA: row tiles per batch entry (see the kernel)
     const int mtiles = ADA ? ((a.M + a.mod_rpb - 1) / a.mod_rpb) * ((a.mod_rpb + TMB - 1) / TMB) : (a.M + TMB - 1) / TMB;
     const dim3 grid(a.N / (PAIR ? 32 : 16), 1, mtiles);
-    auto kern = skinny2_kernel<NW, MTL, PAIR, ADA, NC, WNT, ALDS>;
+    auto kern = skinny2_kernel<NW, MTL, PAIR, ADA, NC, WNT, ALDS, FOLD>;
     if constexpr (LDS > 48 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -597,6 +649,21 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
     const int nw = d->K / 256;  // waves of the two-chunk variants
     KAI0_REQUIRE(d->K % 256 == 0 && (nw == 4 || nw == 8 || nw == 16), "kai0_gemm_skinny_bf16: in-block K needs K in {1024, 2048, 4096}, got %d", d->K);
     const bool ada = d->mod != nullptr;
+    const bool fold = d->rowsq_in != nullptr;
+    if (fold) {
+        KAI0_REQUIRE(!ada && d->mode != 0 && nw == 4 && d->cvec && d->rowsq_parts >= 1 && d->rowsq_parts <= 64 && d->rowsq_ld >= d->M &&
+                         d->a_rpb == 0 && ((uintptr_t)d->cvec % 16) == 0,
+                     "kai0_gemm_skinny_bf16: the folded adaRMS form needs mode 1 / 2, K = 1024, no `mod`, cvec [N] f32 16-byte aligned, "
+                     "1 <= rowsq_parts <= 64, rowsq_ld >= M, identity A rows");
+        a.rowsq_in = d->rowsq_in;
+        a.cvec = d->cvec;
+        a.rowsq_parts = d->rowsq_parts;
+        a.rowsq_ld = d->rowsq_ld;
+        a.eps = d->eps;
+        // the shapes of the adaRMS launches they replace: q|k|v as 8 waves x one 16-row tile (320 blocks), gate|up 8 waves x all four
+        if (d->mode == 1) return launch_skinny2<8, 1, true, false, 1, false, true, true>(a, s);
+        return launch_skinny2<8, 4, true, false, 1, true, true, true>(a, s);
+    }
     if (ada) {
         KAI0_REQUIRE(d->mode != 0 && nw == 4 && d->mod_rpb > 0 && d->mod_ld >= 2 * (int64_t)d->K && d->mod_ld % 4 == 0 &&
                          ((uintptr_t)d->mod % 16) == 0 && d->a_rpb == 0,
@@ -605,6 +672,12 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
         a.mod_ld = d->mod_ld;
         a.mod_rpb = d->mod_rpb;
         a.eps = d->eps;
+    }
+    if (d->rowsq_out != nullptr) {
+        KAI0_REQUIRE(d->mode == 0 && d->rowsq_out_ld >= d->M && d->N / 16 <= 64, "kai0_gemm_skinny_bf16: rowsq_out needs in-block mode 0, "
+                     "rowsq_out_ld >= M, N <= 1024");
+        a.rowsq_out = d->rowsq_out;
+        a.rowsq_out_ld = d->rowsq_out_ld;
     }
     if (d->mode == 0) {
         KAI0_REQUIRE(d->N % 128 == 0, "kai0_gemm_skinny_bf16: in-block mode 0 needs N %% 128 == 0 (8 column tiles per XCD round), got %d", d->N);
@@ -718,7 +791,8 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
         }
         return skinny_inblock(d, a, (hipStream_t)stream);
     }
-    KAI0_REQUIRE(d->mod == nullptr, "kai0_gemm_skinny_bf16: the adaRMS prologue needs split_k == -1");
+    KAI0_REQUIRE(d->mod == nullptr && d->rowsq_in == nullptr && d->rowsq_out == nullptr,
+                 "kai0_gemm_skinny_bf16: the adaRMS prologue / folded form / row statistics need split_k == -1");
     const int tiles = d->N / TN, mtiles = (d->M + TM - 1) / TM;
     if (S > 1) {
         const int64_t need = (int64_t)S * d->M * d->N * 4;

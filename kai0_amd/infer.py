@@ -93,6 +93,10 @@ class InferenceEngine:
         self.fuse_norm = os.environ.get("KAI0_INFER_FUSE_NORM", "1") != "0"
         self._mods_cache = {}
         self.cache_mods = os.environ.get("KAI0_INFER_CACHE_MODS", "1") != "0"
+        # adaRMS folded into the expert's q|k|v and gate|up weights per Euler step (_fold_modulations; KAI0_INFER_FOLD=0: the adaRMS
+        # prologue inside the projection kernels, round 3's form, for A/B runs)
+        self.fold = self.cache_mods and os.environ.get("KAI0_INFER_FOLD", "1") != "0"
+        self._fold_cache = {}
         self._graph = None
         self._graph_steps = None
         self._static_in = None
@@ -239,6 +243,7 @@ class InferenceEngine:
         self.inblock = (os.environ.get("KAI0_INFER_INBLOCK", "1") != "0" and De == 1024 and NQ_ok(H * HD) and self.F in (1024, 2048, 4096)
                         and De % 128 == 0)  # fmt: skip
         self.packed = self.packed and self.inblock and HD == 256 and self.S <= 1024 and self.P % 8 == 0  # (= the in-block stack runs)
+        self.w_qkv_raw, self.w_gu_raw = self.w_qkv, self.w_gu  # row-major stacked copies (the folded per-step weights are cut from them)
         if self.packed:
             self.w_qkv = [ops.pack_skinny_weight(w) for w in self.w_qkv]
             self.w_gu = [ops.pack_skinny_weight(w) for w in self.w_gu]
@@ -377,11 +382,70 @@ class InferenceEngine:
         mods = [(allm[:, (2 * l) * W3 : (2 * l + 1) * W3], allm[:, (2 * l + 1) * W3 : (2 * l + 2) * W3]) for l in range(self.L)]
         return mods, allm[:, 2 * self.L * W3 :]
 
+    def _fold_modulations(self, mods, n_steps: int):
+        """The adaRMS norms in front of the expert's q|k|v and gate|up projections, folded into the weights (kai0hip.h rowsq_in): the
+        modulation of a step is a function of the step's time value and the weights only — the same for every request and every
+        sample of the batch — so with W' = bf16(W (1 + scale)) and c = W shift the projection of the normalised activations is
+        rstd * (x W'^T) + c on the RAW residual stream.  One packed W' and one c per (step, layer, projection): 10 x 18 x (5.2 + 16.8 MB)
+        = 4 GB of the 288 GB, built once per engine; the kernels then carry no row-statistics pass and no per-element normalisation."""
+        De = self.De
+        out = []
+        for step in range(n_steps):
+            r = step * self.B  # (every row of a step holds the same modulation: the time value is shared by the batch)
+            per_layer = []
+            for l in range(self.L):
+                ent = []
+                for w, m in ((self.w_qkv_raw[l], mods[l][0]), (self.w_gu_raw[l], mods[l][1])):
+                    scale, shift = m[r, :De], m[r, De : 2 * De]
+                    wf = w.float()
+                    wp = (wf * (1.0 + scale)[None, :]).to(BF16)
+                    ent.append((ops.pack_skinny_weight(wp) if self.packed else wp.contiguous(), (wf @ shift).contiguous()))
+                per_layer.append(ent)
+            out.append(per_layer)
+        return out
+
     def _gate(self, idx: int, rows):
         """bf16 gate vector(s) of stacked modulation `idx` (2 l: input norm, 2 l + 1: post-attention norm) for `rows`."""
         De = self.De
         c0 = idx * 3 * De + 2 * De
         return self._gates[rows, c0 : c0 + De]
+
+    def _expert_stack_folded(self, xs, sq, step: int, rows, folded):
+        """_expert_stack_inblock with the adaRMS norms folded into the weights: the projections read the raw residual stream, the
+        producers (denoise glue, o_proj, down_proj) hand the rows' partial sums of squares along (`sq`: [64, M] f32, `parts` valid)."""
+        B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
+        M, dev = B * Hs, self.dev
+        cos, sin = self._rope_cs
+        layers = self.pe.gemma_expert.model.layers
+        NQ = H * HD
+        ld = self._mod_ld
+        parts = 1  # the step's first rows come from the glue kernel: one partial per row
+        for l, layer in enumerate(layers):
+            (wq, cq), (wg, cg) = folded[step][l]
+            ops.skinny_gemm(xs, wq, M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2, split_k=-1,
+                            segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
+                                  (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
+                            c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, eps=layer.input_layernorm.eps,
+                            w_packed=self.packed, rowsq_in=sq, rowsq_parts=parts, cvec=cq)  # fmt: skip
+            ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
+                            rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
+                            vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
+            x1 = torch.empty((M, De), dtype=BF16, device=dev)
+            sq1 = torch.empty((De // 16, M), dtype=F32, device=dev)
+            ops.skinny_gemm(self.att_buf, self.w_o[l], M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
+                            a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
+                            residual=xs, ldr=De, w_packed=self.packed, rowsq_out=sq1)  # fmt: skip
+            h = torch.empty((M, F), dtype=BF16, device=dev)
+            ops.skinny_gemm(x1, wg, M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
+                            segs=[(h, F, 0, F, 0)], eps=layer.post_attention_layernorm.eps, w_packed=self.packed,
+                            rowsq_in=sq1, rowsq_parts=De // 16, cvec=cg)  # fmt: skip
+            xs = torch.empty((M, De), dtype=BF16, device=dev)
+            sq = torch.empty((De // 16, M), dtype=F32, device=dev)
+            ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
+                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=self.packed,
+                            rowsq_out=sq)  # fmt: skip
+            parts = De // 16
+        return xs  # the step seam (kai0_denoise_glue) applies the final norm
 
     def _expert_stack_inblock(self, xs, mods, mf, rows, final_norm: bool = True):
         """All expert layers of one denoise step, 6 launches per layer and no partial products: [adaRMS -> q|k|v + RoPE],
@@ -498,6 +562,8 @@ class InferenceEngine:
             if hit is None:  # first (warm-up) run of this schedule: computed eagerly, kept for the engine's lifetime
                 mods, mf = self._modulations(times)
                 hit = self._mods_cache[tuple(times)] = (mods, mf, self._mod_ld if self.skinny else None, self._gates if self.skinny else None)
+                if self.skinny and self.inblock and self.decode_attn and self.glue and self.fold:
+                    self._fold_cache[tuple(times)] = self._fold_modulations(mods, len(times))
             mods, mf = hit[0], hit[1]
             if self.skinny:
                 self._mod_ld, self._gates = hit[2], hit[3]
@@ -519,13 +585,20 @@ class InferenceEngine:
             wout, bout = model.action_out_proj.weight, model.action_out_proj.bias
             eps = self.pe.gemma_expert.model.norm.eps
             xs = torch.empty((M, De), dtype=BF16, device=self.dev)
-            ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs)
+            folded = self._fold_cache.get(tuple(times)) if self.fold else None
+            sq = torch.empty((1, M), dtype=F32, device=self.dev) if folded is not None else None
+            ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs, rowsq_next=sq)
             for step in range(n):
                 rows = slice(step * B, (step + 1) * B)
-                last = self._expert_stack_inblock(xs, mods, mf, rows, final_norm=False)
+                if folded is not None:
+                    last = self._expert_stack_folded(xs, sq, step, rows, folded)
+                else:
+                    last = self._expert_stack_inblock(xs, mods, mf, rows, final_norm=False)
                 xs = torch.empty((M, De), dtype=BF16, device=self.dev) if step + 1 < n else None
+                sq = torch.empty((1, M), dtype=F32, device=self.dev) if (folded is not None and xs is not None) else None
                 ops.denoise_glue(x2, xs=last, mod=mf[rows], mod_ld=self._mod_ld, rows_per_batch=Hs, eps=eps, w_out=wout, b_out=bout,
-                                 dt=dt, w_in=win if xs is not None else None, b_in=bin_ if xs is not None else None, xs_next=xs)
+                                 dt=dt, w_in=win if xs is not None else None, b_in=bin_ if xs is not None else None, xs_next=xs,
+                                 rowsq_next=sq)
             return x_t
         for step in range(len(times)):
             v_t = self._denoise_step(x_t, step, mods, mf)

@@ -148,10 +148,13 @@ def skinny_workspace(M: int, N: int, split_k: int, device) -> torch.Tensor:
 def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int = 0, pair_stride: int = 16, segs=None,
                 split_k: int = 1, workspace=None, a_map=None, c_map=None, gate=None, gate_rpb: int = 0, gate_ld: int = 0,
                 residual=None, ldr: int = 0, rope_cos=None, rope_sin=None, rope_half: int = 0, mod=None, mod_ld: int = 0,
-                mod_rpb: int = 0, eps: float = 1e-6, w_packed: bool = False):  # fmt: skip
+                mod_rpb: int = 0, eps: float = 1e-6, w_packed: bool = False, rowsq_in=None, rowsq_parts: int = 0, cvec=None,
+                rowsq_out=None):  # fmt: skip
     """kai0_gemm_skinny_bf16.  segs = [(dst, ld, n_begin, n_end, rope)].  split_k = -1: the whole contraction inside one block
     (no partial products); with `mod` (f32 view [b][>= 2K], row stride mod_ld) the A operand is adaRMS-normalised on the fly;
-    `w_packed`: W is the output of `pack_skinny_weight` (fragment-major 1-KiB blocks)."""
+    `w_packed`: W is the output of `pack_skinny_weight` (fragment-major 1-KiB blocks).  Folded adaRMS (kai0hip.h): W already
+    carries (1 + scale), `cvec` [N] f32 the shift term, `rowsq_in` [parts, >= M] f32 the producer's partial sums of squares of the
+    rows of A; `rowsq_out` [N / 16, >= M] f32 (mode 0) receives this launch's own partials."""
     for t in (A, W):
         if not t.is_cuda or t.dtype != BF16:
             raise _lib.Kai0HipError("skinny_gemm: expected bf16 CUDA (HIP) tensors; the product path has no CPU fallback")
@@ -185,6 +188,13 @@ def skinny_gemm(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, mode: int =
         if mod.dtype != F32 or not mod.is_cuda or mod.stride(-1) != 1:
             raise _lib.Kai0HipError("skinny_gemm: mod must be an f32 CUDA (HIP) tensor with unit inner stride")
         d.mod, d.mod_ld, d.mod_rpb, d.eps = mod.data_ptr(), mod_ld, mod_rpb, eps
+    if rowsq_in is not None:
+        _chk(rowsq_in, F32, "rowsq_in")
+        _chk(cvec, F32, "cvec")
+        d.rowsq_in, d.cvec, d.rowsq_parts, d.rowsq_ld, d.eps = rowsq_in.data_ptr(), cvec.data_ptr(), rowsq_parts, rowsq_in.stride(0), eps
+    if rowsq_out is not None:
+        _chk(rowsq_out, F32, "rowsq_out")
+        d.rowsq_out, d.rowsq_out_ld = rowsq_out.data_ptr(), rowsq_out.stride(0)
     _lib.call("kai0_gemm_skinny_bf16", C.byref(d), _stream())
 
 
@@ -1550,7 +1560,7 @@ def mse_loss(u, v):
 
 
 def denoise_glue(x_t, *, xs=None, mod=None, mod_ld=0, rows_per_batch=1, eps=1e-6, w_out=None, b_out=None, dt=0.0, w_in=None,
-                 b_in=None, xs_next=None):
+                 b_in=None, xs_next=None, rowsq_next=None):
     """kai0_denoise_glue: close a denoise step (final adaRMS -> action_out_proj -> Euler update of x_t, in place) and / or open
     the next one (action_in_proj -> bf16 suffix embedding) in one launch.  x_t: f32 [rows, A] contiguous."""
     rows, A = x_t.shape[0], x_t.shape[1]
@@ -1559,7 +1569,7 @@ def denoise_glue(x_t, *, xs=None, mod=None, mod_ld=0, rows_per_batch=1, eps=1e-6
         if t is not None and t.dtype != F32:
             raise TypeError("denoise_glue: x_t, weights, biases and modulations are f32")
     _lib.call("kai0_denoise_glue", _p(xs), _p(mod), mod_ld, rows_per_batch, eps, _p(w_out), _p(b_out), x_t.data_ptr(), dt, _p(w_in),
-              _p(b_in), _p(xs_next), rows, D, A, _stream())
+              _p(b_in), _p(xs_next), rows, D, A, _p(rowsq_next), _stream())
 
 
 def euler_step_(x, v, dt: float):

@@ -1005,6 +1005,50 @@ def test_persistent_gemm_is_bit_identical_to_one_block_per_tile(ops, case):
         assert rel_err(res[2][0], ref) < 5e-3
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_skinny_folded_adarms_and_producer_row_statistics(ops, B):
+    """The folded form of the adaRMS projections of the denoise loop (kai0hip.h rowsq_in): the producer launch (o_proj-style mode 0
+    with gate + residual) hands over per-column-tile sums of squares of the rows it stores, the consumer multiplies the RAW rows
+    by W' = bf16(W (1 + scale)) and applies rstd and c = W shift to the f32 sum.  Against fp32 math of the unfolded definition
+    (modeling_gemma.py:49-104 + the Linear) and against the adaRMS-prologue form it replaces (other rounding points: tolerance)."""
+    Hs, K, F, Kp = 50, 1024, 4096, 2048
+    M = B * Hs
+    a_prev = rnd(M, Kp, seed=1)
+    w_prev = rnd(K, Kp, seed=2, scale=0.03)
+    gate = rnd(B, K, seed=3)
+    res = rnd(M, K, seed=4)
+    x = torch.empty(M, K, dtype=BF16, device=dev())
+    sq = torch.zeros(K // 16, M, dtype=F32, device=dev())
+    ops.skinny_gemm(a_prev, w_prev, M=M, N=K, K=Kp, lda=Kp, ldw=Kp, split_k=-1, segs=[(x, K, 0, K, 0)], gate=gate, gate_rpb=Hs,
+                    gate_ld=K, residual=res, ldr=K, rowsq_out=sq)
+    assert torch.allclose(sq.sum(0), x.float().pow(2).sum(1), rtol=1e-5, atol=1e-3)  # the partials add up to the rows' sums of squares
+    mod = rnd(B, 3 * K, dtype=F32, seed=9, scale=0.3)
+    scale, shift = mod[0, :K], mod[0, K : 2 * K]  # (the engine's modulation is the same for every sample of a step)
+    modb = mod[:1].expand(B, -1).contiguous()
+    wgu = rnd(2 * F, K, seed=5, scale=0.05)
+    wp = (wgu.float() * (1 + scale)[None, :]).to(BF16)
+    cvec = (wgu.float() @ shift).contiguous()
+    h = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, wp, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, split_k=-1, segs=[(h, F, 0, F, 0)], eps=1e-6,
+                    rowsq_in=sq, rowsq_parts=K // 16, cvec=cvec)
+    h_mod = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, wgu, M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, split_k=-1, segs=[(h_mod, F, 0, F, 0)], mod=modb,
+                    mod_ld=3 * K, mod_rpb=Hs, eps=1e-6)
+    xf = x.float()
+    yn = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)) * (1 + scale) + shift
+    gu = yn @ wgu.float().t()
+    ref = torch.nn.functional.gelu(gu[:, :F], approximate="tanh") * gu[:, F:]
+    e_fold, e_mod = rel_err(h, ref), rel_err(h_mod, ref)
+    print(f"folded vs fp32 {e_fold:.3e}; adaRMS-prologue form vs fp32 {e_mod:.3e}; folded vs prologue form {rel_err(h, h_mod):.3e}")
+    assert e_fold < 8e-3 and e_fold < 1.5 * e_mod + 1e-3
+    # packed weights and a single partial (the step's first layer: the glue kernel writes one sum per row): same result
+    sq1 = x.float().pow(2).sum(1)[None].contiguous()
+    h2 = torch.zeros(M, F, dtype=BF16, device=dev())
+    ops.skinny_gemm(x, ops.pack_skinny_weight(wp), M=M, N=2 * F, K=K, lda=K, ldw=K, mode=2, pair_stride=F, split_k=-1,
+                    segs=[(h2, F, 0, F, 0)], eps=1e-6, rowsq_in=sq1, rowsq_parts=1, cvec=cvec, w_packed=True)
+    assert rel_err(h2, h) < 1e-3
+
+
 @pytest.mark.parametrize("n", [3, 9])
 def test_siglip_attention_forward_dedicated_kernel(ops, n):
     """kai0_siglip_attn_fwd at the real tower's shape (256 tokens, 16 heads x 72): n = 3 runs the four-blocks-per-head form (B = 1

@@ -22,7 +22,9 @@ SWITCHES = [
     ({"KAI0_INFER_GRAPH": "0"}, True),                          # eager launches instead of the hipGraph replay
     ({"KAI0_GEGLU_PAIR": "0"}, False),                          # gate GEMM + up GEMM (act 2) instead of the pair GEMM (the GEMMs are
                                                                 # bit-identical; the backward's operand layout differs)
-    ({"KAI0_INFER_CACHE_MODS": "0"}, True),                     # modulation table recomputed per call
+    ({"KAI0_INFER_CACHE_MODS": "0"}, False),                    # modulation table recomputed per call (hence no folded adaRMS weights)
+    ({"KAI0_INFER_FOLD": "0", "KAI0_ATTN_STORE_P": "1", "KAI0_GEMM_PERSIST": "0"}, False),  # round 3's forms: adaRMS prologue in the
+                                                                # denoise kernels, stored-P attention, one GEMM block per tile
     ({"KAI0_SKIP_DEAD_PREFIX": "0"}, True),                     # the last layer's dead prefix o_proj / MLP computed
     ({"KAI0_ZERO_GRADS": "full"}, True),                        # flat gradient buffers cleared every step
     ({"KAI0_ATTN_QT": "2", "KAI0_ATTN_ONEPASS": "0"}, False),   # four-wave attention blocks; SigLIP inference attention in two passes
