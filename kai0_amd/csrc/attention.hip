@@ -80,7 +80,7 @@ template <int NKS, int VC, int QT, int OP = 0, int RB = 128>
 __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int WAVES = RB / (16 * QT);
     constexpr int NST = RB == 64 ? 1 : 2;  // staging buffers of the two-pass form
-    static_assert(RB == 128 || (RB == 64 && OP <= 0 && QT == 1), "64-row blocks: two passes / online, one 16-row tile per wave");
+    static_assert(RB == 128 && QT == 1, "128-row blocks of eight waves (the 64-row / four-wave forms were measured slower and removed)");
     constexpr int OMT = VC / 16;
     constexpr int KSTEPS = NKS * 2;                 // 32-wide contraction steps over the head dim
     constexpr int K_BYTES = NKS * 8192;             // NKS x [64 keys][64 d] bf16
@@ -615,15 +615,11 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d->lse == nullptr || d->s_lse >= d->rows, "kai0_attn_fwd: s_lse=%lld < rows", (long long)d->s_lse);
     static const int ablate = [] { const char* e = getenv("KAI0_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
-    static const int nt_p = [] { const char* e = getenv("KAI0_ATTN_NT_P"); return e ? atoi(e) : 1; }();
-    p.nt_p = nt_p;
-    static const int kc_lds = [] { const char* e = getenv("KAI0_ATTN_KC_LDS"); return e ? atoi(e) : 1; }();
+    p.nt_p = 1;
     const int kc_keys = ((d->Sk + 63) / 64) * 64;
-    p.kc_lds_keys = (kc_lds && kc_keys <= KC_LDS_MAX) ? kc_keys : 0;  // longer key ranges read their codes from global
+    p.kc_lds_keys = kc_keys <= KC_LDS_MAX ? kc_keys : 0;  // longer key ranges read their codes from global
     const int batch = d->batch > 0 ? d->batch : 1;
-    static const int rb64 = [] { const char* e = getenv("KAI0_ATTN_RB64"); return e ? atoi(e) : 0; }();
-    const bool small = rb64 && d->HD > 128;  // (joint attention only)
-    dim3 grid((d->rows + (small ? 63 : 127)) / (small ? 64 : 128), batch, 1);
+    dim3 grid((d->rows + 127) / 128, batch, 1);
     hipStream_t s = (hipStream_t)stream;
 #define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP, RB)                                                                          \
     do {                                                                                                          \
@@ -638,37 +634,23 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
         }                                                                                                         \
         hipLaunchKernelGGL(kern, grid, dim3(RB / (16 * QT) * 64), LDS, s, p);                                    \
     } while (0)
-    // KAI0_ATTN_QT=2: the former four-wave blocks; KAI0_ATTN_ONEPASS=0: always two passes (diagnostics)
-    static const int qt = [] { const char* e = getenv("KAI0_ATTN_QT"); return e ? atoi(e) : 1; }();
-    static const int onepass = [] { const char* e = getenv("KAI0_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
-    // (Measured and rejected, round 3: the two wave groups of pass 2 one barrier slot apart — group 0 in [logits, softmax, P store]
-    // while group 1 is in [P V] — 1.095 against 0.965 ms: the phases are latency-bound, two lockstep waves per SIMD already cover
-    // each other, and a slot lasts as long as its longer phase.)
-    // one pass with an online softmax whenever the caller does not ask for P (d->online: 0 = that rule, 1 = must, 2 = never;
-    // KAI0_ATTN_ONLINE=0 turns the rule off for A/B runs).  For <= 256 keys at HD <= 128 (SigLIP) the resident single-pass form is
-    // exact AND one pass, so it stays.
-    static const int online_env = [] { const char* e = getenv("KAI0_ATTN_ONLINE"); return e ? atoi(e) : 1; }();
+    // (Measured and rejected, round 3: the two wave groups of pass 2 one barrier slot apart — 1.095 against 0.965 ms; four-wave
+    // blocks with two 16-row tiles per wave — 0.83 against 0.66 ms one-pass; 64-row blocks, two per CU — 0.915 against 0.930 ms two-pass.
+    // Round 4: the logits of tile kt + 1 computed ahead of the softmax of tile kt, K staged one tile ahead of V — 0.536 against
+    // 0.526 ms; the same with the two waves of a SIMD walking the phases in different orders spilled 62 registers at HD = 256.
+    // KAI0_ATTN_ABLATE on the one-pass loop: Q K^T 0.11, P V 0.11, LDS-DMA issue 0.10, everything else — mask / rounding / max / exp
+    // VALU, two cross-lane shuffles, barrier, prologue and the row-per-lane O stores — 0.24 of the 0.53 ms, serial per wave.)
+    // One pass with an online softmax whenever the caller does not ask for P (d->online: 0 = that rule, 1 = must, 2 = never).  For
+    // <= 256 keys at HD <= 128 on small grids the resident single-pass form is exact AND one pass, so it stays.
     KAI0_REQUIRE(d->online != 1 || d->P == nullptr, "kai0_attn_fwd: the one-pass form does not produce P");
-    const bool online = d->P == nullptr && d->online != 2 && (d->online == 1 || online_env);
-    static const int op_grid = [] { const char* e = getenv("KAI0_ATTN_ONEPASS_GRID"); return e ? atoi(e) : 512; }();
+    const bool online = d->P == nullptr && d->online != 2;
     if (d->HD <= 128) {
-        if (qt == 2 && !online) KAI0_ATTN_LAUNCH(2, 128, 2, 0, 128);
-        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= op_grid) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
-        else if (online) KAI0_ATTN_LAUNCH(2, 128, 1, -1, 128);
         // 256 keys = 4 resident tiles (144 KiB, one block per CU): wins when the grid is at most a round or two of the chip
-        // (B = 1 inference: 26 -> 19 us); with thousands of blocks the two-pass form's two 80-KiB blocks per CU are as fast
-        else if (onepass && d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
+        if (d->Sk <= 256 && (int64_t)grid.x * grid.y <= 512) KAI0_ATTN_LAUNCH(2, 128, 1, 4, 128);
+        else if (online) KAI0_ATTN_LAUNCH(2, 128, 1, -1, 128);
         else KAI0_ATTN_LAUNCH(2, 128, 1, 0, 128);
     } else {
-        // (Measured and rejected, round 4: the logits of tile kt + 1 computed ahead of the softmax of tile kt, K staged one tile ahead
-        // of V — 0.536 against 0.526 ms; the same with the two waves of a SIMD walking the phases in different orders spilled 62
-        // registers at HD = 256: 1.0-1.5 ms.  KAI0_ATTN_ABLATE on this loop: Q K^T 0.11, P V 0.11, LDS-DMA issue 0.10, everything else
-        // — mask / rounding / max / exp VALU, two cross-lane shuffles, barrier, prologue and the row-per-lane O stores — 0.24 of the
-        // 0.53 ms, serial per wave.)
-        if (online && qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, -1, 128);
-        else if (online) KAI0_ATTN_LAUNCH(4, 256, 1, -1, 128);
-        else if (qt == 2) KAI0_ATTN_LAUNCH(4, 256, 2, 0, 128);
-        else if (small) KAI0_ATTN_LAUNCH(4, 256, 1, 0, 64);
+        if (online) KAI0_ATTN_LAUNCH(4, 256, 1, -1, 128);
         else KAI0_ATTN_LAUNCH(4, 256, 1, 0, 128);
     }
 #undef KAI0_ATTN_LAUNCH

@@ -262,12 +262,12 @@ KAI0_API int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void
     }
     // few query tiles (B = 1: 25): eight key ranges / eight head-dim slices per tile instead of four, so that 200 blocks share
     // the staging of the caches instead of 100
-    static const int fine = [] { const char* e = getenv("KAI0_DEC_FINE"); return e ? atoi(e) : 1; }();
+    const int fine = 1;
     // Range-major grids: a workgroup's XCD is its linear id % 8 (tools/probes/xcc_map.hip), so with the key range / head-dim slice in
     // blockIdx.x (8 or 4 of them) every block that stages the same rows of the K / V cache runs on the same XCD and the rows cross
     // the fabric once per launch instead of once per XCD (query-tile-major: 5.9 / 10.9 MB fetched per launch for 0.7 / 1.3 MB of
-    // operands, profiles/r03_infer_chunk_pmc.txt).  KAI0_DEC_RANGE_MAJOR=0: the former order.
-    static const int rmaj = [] { const char* e = getenv("KAI0_DEC_RANGE_MAJOR"); return e ? atoi(e) : 1; }();
+    // operands, profiles/r03_infer_chunk_pmc.txt).
+    const int rmaj = 1;
     p.range_major = rmaj;
     auto grid = [&](int ranges) { return rmaj ? dim3(ranges, qt, batch) : dim3(qt, ranges, batch); };
     if (fine && (int64_t)qt * batch <= 32) {

@@ -42,7 +42,6 @@ struct SbArgs {
     int64_t E;   // row stride (elements) of q / k / v / dO / O: NH * 72
     int64_t Eg;  // row stride of dq / dk / dv (>= E: the three may be column slices of one [rows][3 E] buffer)
     float scale;
-    int dbg;  // diagnostics (KAI0_SB_DBG): 1 = stop after staging + D, 2 = stop after phase A, 3 = skip phase A
 };
 
 __device__ __forceinline__ bf16x8 sb_zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -92,7 +91,7 @@ __device__ __forceinline__ bf16_t sb_prob(float acc, float scale, float lse) { r
 
 template <bool RC, int SB_LDR>
 __global__ __launch_bounds__(512, (RC && SB_LDR == 72) ? 4 : 1) void siglip_attn_bwd_kernel(const SbArgs p) {
-    static_assert(SB_LDR == 104 || (RC && SB_LDR == 72), "tile row stride");
+    static_assert((!RC && SB_LDR == 104) || (RC && SB_LDR == 72), "tile row stride: padded for the stored-P form, unpadded (two blocks per CU) for the recompute form");
     constexpr int SB_TILE = sb_tile_bytes(SB_LDR);
     auto sb_rowfrag = [](const bf16_t* tile, int row, int cc, int g) { return sb_rowfrag_t<SB_LDR>(tile, row, cc, g); };
     extern __shared__ __attribute__((aligned(16))) char sbm[];
@@ -140,9 +139,8 @@ __global__ __launch_bounds__(512, (RC && SB_LDR == 72) ? 4 : 1) void siglip_attn
 
     // ================= phase A: dQ for query rows [32 wave, +32) ==========================================
     const int arow = 8 * (l15 >> 2) + (l15 & 3);  // row of a 32-row group fed to A-row l15 of tile 0 (tile 1: + 4)
-    if (p.dbg == 1) return;
 #pragma unroll 1
-    for (int c = p.dbg == 3 ? 2 : 0; c < 2; ++c) {
+    for (int c = 0; c < 2; ++c) {
         const int q0 = 32 * wave + 16 * c;
         bf16x8 dof[3];
 #pragma unroll
@@ -214,7 +212,6 @@ __global__ __launch_bounds__(512, (RC && SB_LDR == 72) ? 4 : 1) void siglip_attn
     }
     __syncthreads();
 
-    if (p.dbg == 2) return;
     // ================= phase B: dK, dV for keys [32 wave, +32) ============================================
     sb_stage2<SB_LDR>(qg, dOg, p.E, T0, T1, tid);
     if constexpr (RC) {
@@ -376,8 +373,8 @@ __global__ __launch_bounds__(512, (RC && SB_LDR == 72) ? 4 : 1) void siglip_attn
 // order) in a single pass:
 //   wave = 16 query rows at a time: S^T = K Q^T in 8 groups of 32 keys (K rows permuted so that lane (q, g) holds 8 consecutive
 //   keys of the group = the B fragment of O^T += V^T P^T), V^T fragments through the transpose read of the row-major V tile.
-// <NWV waves, CH 16-row chunks per wave>: <8, 2> = a whole head (256 rows) per block (training: 1536 blocks, two per CU), <4, 2> two
-// blocks per head (A/B), <4, 1> four 64-row blocks per head (B = 1 inference: 48 heads then cover 192 CUs).  lse (optional) = log-sum-exp of the rounded logits, for the recompute backward.
+// <NWV waves, CH 16-row chunks per wave>: <8, 2> = a whole head (256 rows) per block (training: 1536 blocks, two per CU), <4, 1> four
+// 64-row blocks per head (B = 1 inference: 48 heads then cover 192 CUs).  lse (optional) = log-sum-exp of the rounded logits, for the recompute backward.
 struct SfArgs {
     const bf16_t *q, *k, *v;
     bf16_t* o;
@@ -511,21 +508,15 @@ static int siglip_attn_bwd_launch(const void* q, const void* k, const void* v, c
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel<false, 104>, hipFuncAttributeMaxDynamicSharedMemorySize, sb_lds_bytes(false, 104));
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel<true, 104>, hipFuncAttributeMaxDynamicSharedMemorySize, sb_lds_bytes(true, 104));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_bwd_kernel<true, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, sb_lds_bytes(true, 72));
         KAI0_REQUIRE(e == hipSuccess, "kai0_siglip_attn_bwd: cannot reserve LDS: %s", hipGetErrorString(e));
         attr_set = true;
     }
     SbArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)P, lse,
-             (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, NH, (int64_t)NH * HD, ld_grad, scale, 0};
-    static const int dbg = [] { const char* e = getenv("KAI0_SB_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
-    // KAI0_SB_LDR=104: the padded tiles (one block per CU) for A/B runs
-    static const int ldr = [] { const char* e = getenv("KAI0_SB_LDR"); return e ? atoi(e) : 72; }();
-    if (lse != nullptr && ldr == 72)
+             (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, NH, (int64_t)NH * HD, ld_grad, scale};
+    // (the recompute form with padded 104-wide tiles — one block per CU — measured 0.376 against 0.301 ms per layer: removed)
+    if (lse != nullptr)
         hipLaunchKernelGGL((siglip_attn_bwd_kernel<true, 72>), dim3(n_img * NH), dim3(512), sb_lds_bytes(true, 72), (hipStream_t)stream, a);
-    else if (lse != nullptr)
-        hipLaunchKernelGGL((siglip_attn_bwd_kernel<true, 104>), dim3(n_img * NH), dim3(512), sb_lds_bytes(true, 104), (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((siglip_attn_bwd_kernel<false, 104>), dim3(n_img * NH), dim3(512), sb_lds_bytes(false, 104), (hipStream_t)stream, a);
     return kai0_check_launch("kai0_siglip_attn_bwd");
@@ -558,19 +549,16 @@ KAI0_API int kai0_siglip_attn_fwd(const void* q, const void* k, const void* v, v
     constexpr int LDS = 2 * sb_tile_bytes(72) + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)siglip_attn_fwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         KAI0_REQUIRE(e == hipSuccess, "kai0_siglip_attn_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
         attr_set = true;
     }
     SfArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, NH, ldq, ldk, ldv, ldo, sq, sk, sv, so, scale};
     const int heads = n_img * NH;
     // few heads (B = 1 inference: 48): four 64-row blocks per head so that the launch covers the chip
-    // KAI0_SF_ROWS=128: two four-wave blocks per head instead of one eight-wave block (A/B)
-    static const int rows = [] { const char* e = getenv("KAI0_SF_ROWS"); return e ? atoi(e) : 256; }();
+    // (two four-wave blocks per head instead of one eight-wave block: 0.153 against 0.126 ms per layer at B = 32)
     if (heads <= 128) hipLaunchKernelGGL((siglip_attn_fwd_kernel<4, 1>), dim3(heads, 4), dim3(256), LDS, (hipStream_t)stream, a);
-    else if (rows == 128) hipLaunchKernelGGL((siglip_attn_fwd_kernel<4, 2>), dim3(heads, 2), dim3(256), LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((siglip_attn_fwd_kernel<8, 2>), dim3(heads, 1), dim3(512), LDS, (hipStream_t)stream, a);
     return kai0_check_launch("kai0_siglip_attn_fwd");
 }

@@ -270,7 +270,8 @@ __device__ __forceinline__ void lds_barrier() {
 template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
-    static_assert(SCH == 0 || (PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4) || (SCH == 3 && PP && NS == 4), "quadrant schedule: 256x256x64");
+    static_assert(SCH == 0 || (SCH == 1 && PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4) || (SCH == 3 && PP && NS == 4), "schedules: 0 plain / two-buffer ping-pong, 1 quadrant (256x256x64), 3 ring (256x256x32)");
+    static_assert(!(PP && NS == 4) || SCH == 3, "the ring runs with every DMA piece between the MFMA rows");
     static_assert(NS >= 2 && (!PP || NS == 2 || (NS == 4 && BKT == 32)), "stages");
     static_assert(BKT == 64 || BKT == 32, "K-tile depth");
     constexpr int BK = BKT;
@@ -1734,14 +1735,14 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // few 128x128 tiles (at most one block per CU): nothing else hides the load latency -> 4-stage pipeline
     const int64_t small_blocks = (int64_t)((d->M + 127) / 128) * ((p.N + 127) / 128) * batch * (split > 1 ? split : 1);
     const bool deep = forced ? forced == 2 : (small_blocks <= 256 && p.k_chunk >= 256);
-    // forced: 4 = 256x256 plain, 5 = 256x256 two-buffer ping-pong (all layouts), 6 = ring for NT only, 7 = ring for all
-    // measured (MLP shapes, random data): the ring wins +21 % for the transpose-read layout (TN wgrads: 512-B source rows,
-    // so a 32-deep sub-tile still moves whole cache lines) and loses up to 17 % for NT (64-B source rows = half lines,
-    // every line crosses the fabric twice), which keeps the two-buffer ping-pong.
-    // (act 6 selects its second weight per DMA piece of a 64-deep K-tile: it never runs on the 32-deep ring, whatever is forced)
-    const bool ring = d->act != 6 && (forced ? forced >= 6 && (forced == 7 || (!d->a_kc && !d->b_kc)) : (!d->a_kc && !d->b_kc));
-    // forced 8: 384x256x64 plain loop (NT / NN only): 20 % fewer staged bytes per FLOP than 256x256
-    // forced 9 / 10: the quadrant schedule for NT (DMA pieces after the fragment reads / between the MFMAs), others as picked
+    // forced (KAI0_GEMM_CFG / kai0_gemm_set_cfg, A/B runs): 1 / 2 = 128x128 with 2 / 4 stages, 4 = 256x256 plain loop, 5 = 256x256
+    // two-buffer ping-pong for every layout.  Measured (MLP shapes, random data): the 32-deep ring wins +21 % for the transpose-read
+    // layout (TN wgrads: 512-B source rows, so a 32-deep sub-tile still moves whole cache lines) and loses up to 17 % for NT (64-B
+    // source rows = half lines), which runs the quadrant schedule (+6..10 % over the two-buffer ping-pong, 1.37 PFLOP/s at 8192^3).
+    // (Act 6 selects its second weight per DMA piece of a 64-deep K-tile: never on the ring.)  Removed after measurement: a 384x256
+    // plain tile (equal to the ping-pong, spilled), the quadrant schedule with its DMA pieces between the MFMAs, the ring with two
+    // pieces per slot kind (-0.9 %), the ring for NT.
+    const bool ring = !forced && d->act != 6 && !d->a_kc && !d->b_kc;
     // persistent NT kernel with the dynamic tile queue (KAI0_GEMM_PERSIST: 0 never, 1 = the rule below, 2 = every eligible NT launch)
     const int persist = g_gemm_persist;
     const bool ps_ok = !forced && persist && big && d->a_kc && d->b_kc && batch == 1 && split == 1 &&
@@ -1772,16 +1773,10 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
         hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(nblk), dim3(512), LDS, s, p, ctr);
         return kai0_check_launch("kai0_gemm_bf16 (persistent)");
     }
-    if (forced == 8 && d->a_kc) rc = launch_cfg<2, 4, 12, 4, false>(d, p, batch, s);
-    else if (forced == 9) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
-    else if (forced == 10) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 2>(d, p, batch, s);
-    else if (forced == 11 && !d->a_kc && !d->b_kc && d->act != 6) rc = launch_cfg<2, 4, 8, 4, true, 4, 32>(d, p, batch, s);  // the former ring: two of a sub-tile's four DMA pieces in the load slot
-    // ring with every DMA piece (and its offset arithmetic) between the MFMA rows: +0.9 % over two pieces per slot kind on the TN shapes
-    else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32, 3>(d, p, batch, s);
+    // TN: ring with every DMA piece (and its offset arithmetic) between the MFMA rows
+    if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32, 3>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
-    // NT: quadrant schedule (measured +6..10 % over the two-buffer ping-pong on every pi0.5 shape, 1.37 PFLOP/s at 8192^3);
-    // KAI0_GEMM_CFG=5 forces the former for all layouts
-    else if (big && d->b_kc && forced != 5) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);
+    else if (big && d->b_kc && forced != 5) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);  // NT: quadrant schedule
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
     else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);
     else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);

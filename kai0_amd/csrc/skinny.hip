@@ -686,40 +686,22 @@ int skinny_inblock(const kai0_skinny_desc* d, SkinnyArgs& a, hipStream_t s) {
         // slice through their XCD's L2.  Measured in the chunk (us per launch, K = 2048 / 4096): 6.9 / 10.3; with non-temporal loads
         // (each block streams its own copy from the fabric) 8.6 / 13.9; two row tiles per block 8.8 / 14.1; all four in one block
         // (weights once, 1024-thread blocks) 13.4 / 33.
-        static const int variant = [] { const char* e = getenv("KAI0_SK2_VARIANT"); return e ? atoi(e) : 0; }();
-        if (variant == 1) {  // half the waves, four chunks of K each
-            if (nw == 8) return launch_skinny2<4, 1, false, false, 4, false>(a, s);
-            if (nw == 16) return launch_skinny2<8, 1, false, false, 4, false>(a, s);
-        }
-        static const int alds = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 3; }();
-        if (alds & 1) {  // A rows through LDS (see the kernel)
-            if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false, true>(a, s);
-            if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false, true>(a, s);
-            return launch_skinny2<16, 1, false, false, 2, false, true>(a, s);
-        }
-        if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false>(a, s);
-        if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false>(a, s);
-        return launch_skinny2<16, 1, false, false, 2, false>(a, s);
+        // (also measured and removed: half the waves with four chunks of K each; A fragments straight from global instead of through
+        // LDS — round 2's form, +0.6 ms per chunk)
+        if (nw == 4) return launch_skinny2<4, 1, false, false, 2, false, true>(a, s);
+        if (nw == 8) return launch_skinny2<8, 1, false, false, 2, false, true>(a, s);
+        return launch_skinny2<16, 1, false, false, 2, false, true>(a, s);
     }
     KAI0_REQUIRE(nw == 4, "kai0_gemm_skinny_bf16: in-block modes 1 / 2 are built for K = 1024 (got %d)", d->K);
-    // tens digit: q|k|v launch, ones digit: gate|up launch.  With the A rows staged through LDS (chunk of 10 Euler steps, one box):
-    // q|k|v as 8 waves x one 16-row tile per block (320 blocks; digit 2) 8.69 ms of denoise, 8 waves x two tiles (1) 8.60-8.70,
-    // 4 waves x two tiles (3, the choice before the staging) 8.83; gate|up keeps all four row tiles in one block (0)
-    static const int pv_all = [] { const char* e = getenv("KAI0_SK2_PAIR_VARIANT"); return e ? atoi(e) : 20; }();
-    const int pv = d->mode == 1 ? pv_all / 10 : pv_all % 10;  // tens digit: q|k|v launch, ones digit: gate|up launch
-    static const int alds2 = [] { const char* e = getenv("KAI0_SK2_ALDS"); return e ? atoi(e) : 3; }();
-    if (ada && (alds2 & 2)) {
+    // With the A rows staged through LDS (chunk of 10 Euler steps, one box): q|k|v as 8 waves x one 16-row tile per block (320
+    // blocks) 8.69 ms of denoise, 8 waves x two tiles 8.60-8.70, 4 waves x two tiles (the choice before the staging) 8.83; gate|up
+    // keeps all four row tiles in one block.  The adaRMS-prologue form (`mod`) is the A/B alternative of the folded form above.
+    if (ada) {
         // the adaRMS prologue reads A with identity rows (a_rpb == 0), so the coalesced tile load applies as is
-        if (pv == 3) return launch_skinny2<4, 2, true, true, 2, false, true>(a, s);
-        if (pv == 0) return launch_skinny2<8, 4, true, true, 1, true, true>(a, s);
-        if (pv == 1) return launch_skinny2<8, 2, true, true, 1, false, true>(a, s);
-        if (pv == 2) return launch_skinny2<8, 1, true, true, 1, false, true>(a, s);
+        if (d->mode == 1) return launch_skinny2<8, 1, true, true, 1, false, true>(a, s);
+        return launch_skinny2<8, 4, true, true, 1, true, true>(a, s);
     }
-    if (ada && pv == 1) return launch_skinny2<8, 2, true, true, 1, false>(a, s);
-    if (ada && pv == 2) return launch_skinny2<8, 1, true, true, 1, false>(a, s);
-    if (ada && pv == 3) return launch_skinny2<4, 2, true, true, 2, false>(a, s);
-    if (ada && pv == 4) return launch_skinny2<4, 1, true, true, 2, false>(a, s);
-    return ada ? launch_skinny2<8, 4, true, true, 1>(a, s) : launch_skinny2<4, 4, true, false>(a, s);
+    return launch_skinny2<4, 4, true, false>(a, s);
 }
 
 }  // namespace
@@ -803,13 +785,9 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
         a.ws = (float*)d->workspace;
     }
     const dim3 grid(tiles, S, mtiles);
-    // 8 waves (KAI0_SKINNY_NW8=1) measured identical to 4 on the denoise loop (24.44 vs 24.45 ms per chunk): the q|k|v and
-    // gate|up launches are not short of loads in flight
-    static const int nw8 = [] { const char* e = getenv("KAI0_SKINNY_NW8"); return e ? atoi(e) : 0; }();
+    // (8 waves measured identical to 4 on the denoise loop, 24.44 vs 24.45 ms per chunk: removed)
     if (a.k_blk == 512)
         hipLaunchKernelGGL((skinny_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (nw8)
-        hipLaunchKernelGGL((skinny_kernel<1, 8>), grid, dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((skinny_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return kai0_check_launch("kai0_gemm_skinny_bf16");

@@ -275,9 +275,6 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-_SPLIT_RULE = os.environ.get("KAI0_SPLIT_RULE", "new")
-
-
 def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
     """Split-K factor for a GEMM with few 128x128 output tiles: spread the contraction over the chip's ~512 block slots
     (256 CUs x 2 blocks) without making a chunk shorter than 4 K-tiles.  Covers both the long-contraction wgrads
@@ -287,8 +284,6 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
         return 1
     if M <= 128:  # one row of tiles: pure weight streaming, latency-bound -> chunks as short as 2 K-tiles
         return max(1, min(32, 768 // tiles, K // 128))
-    if _SPLIT_RULE == "old":
-        return max(1, min(16, 768 // tiles, K // 256))
     # a few hundred to a few thousand rows (the action expert at B = 32, the B = 1 prefix pass): measured on MI355X
     # (tools/expert_gemm_probe.py, us per call over split 1..8): ~400 blocks of 128x128 in total with chunks of >= 768 is the
     # optimum; the former rule (up to 768 blocks, chunks down to 256) cost 20-60 % on these shapes
@@ -301,12 +296,11 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
 # fewer running blocks stages its tiles faster.  Exact pi0.5 shapes at B = 32 first, then the rule they follow.
 _WGRAD_SPLIT = {(1152, 4304, 24576): 3, (4304, 1152, 24576): 3, (3456, 1152, 24576): 2, (1152, 1152, 24576): 6,
                 (2560, 2048, 30976): 3, (2048, 2048, 30976): 4}  # fmt: skip
-_WGRAD_SPLIT_TUNED = os.environ.get("KAI0_WGRAD_SPLIT", "tuned") != "old"
 
 
 def pick_split_k_wgrad(M: int, N: int, K: int) -> int:
     t256 = ((M + 255) // 256) * ((N + 255) // 256)
-    if not _WGRAD_SPLIT_TUNED or t256 >= 200 or K < 4096:
+    if t256 >= 200 or K < 4096:
         return pick_split_k(M, N, K)
     return _WGRAD_SPLIT.get((M, N, K)) or max(1, min(6, 256 // t256, K // 2048))
 
@@ -929,7 +923,7 @@ class GegluMlpFn(torch.autograd.Function):
         return dx, _grad_ret(wg, dwg), _grad_ret(wu, dwu), _grad_ret(wd, dwd), (dout if ctx.has_res else None)
 
 
-_PAD_MLP_ROWS = os.environ.get("KAI0_PAD_MLP_ROWS", "1") != "0"  # diagnostics: 0 = unpadded [M, F] intermediates
+_PAD_MLP_ROWS = True  # [M, F] intermediates with rows padded to 128 bytes (F = 4304: +15-18 % on the GEMMs that touch them)
 
 
 class GeluMlpFn(torch.autograd.Function):
@@ -1246,9 +1240,6 @@ def attn_fwd(Q, K, V, O, P, *, rows, Sk, HD, H=1, q0=0, batch=1, batch_inner=1, 
     _lib.call("kai0_attn_fwd", C.byref(d), _stream())
 
 
-_ATTN_FWD_GEMM = os.environ.get("KAI0_ATTN_FWD", "fused") == "gemm"
-
-
 # KAI0_ATTN_STORE_P=1: the round-3 training attention (exact two-pass forward that stores P, backward reads it) for A/B runs
 _ATTN_STORE_P = os.environ.get("KAI0_ATTN_STORE_P", "0") == "1"
 
@@ -1269,18 +1260,6 @@ def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H
                  sQ=(S_ld * H * HD, 0), sK=(S_ld * HD, 0), sV=(S_ld * HD, 0), sO=(S_ld * H * HD, 0), qcode=qcode, kcode=kcode,
                  scale=scale, q_off=q0 * H * HD, o_off=q0 * H * HD, lse=lse)
         return att, lse
-    if _ATTN_FWD_GEMM and want_probs and HD % 8 == 0:
-        # three launches: logits GEMM (scale in the epilogue), masked softmax in place, P V GEMM
-        probs = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
-        gemm(q_all, k_all, probs, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
-             sB=(S_ld * HD, 0), sC=(M * S_ld, 0), scale=scale, a_off_elems=q0 * H * HD)  # fmt: skip
-        _lib.call("kai0_softmax_mask_fwd", probs.data_ptr(), probs.data_ptr(), _p(qcode), _p(kcode), Bn, Sq, H, Sk, S_ld,
-                  M * S_ld, q0, qcode.stride(0) if qcode is not None else 0, kcode.stride(0) if kcode is not None else 0,
-                  _stream())  # fmt: skip
-        att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-        gemm(probs, v_all, att, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
-             sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0), c_off_elems=q0 * H * HD)  # fmt: skip
-        return att, probs
     probs = torch.empty((Bn, M, S_ld), dtype=BF16, device=dev) if want_probs else None
     att = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
     attn_fwd(q_all, k_all, v_all, att, probs, rows=M, Sk=Sk, HD=HD, H=H, q0=q0, batch=Bn, ldq=HD, ldk=HD, ldv=HD, ldo=HD,
@@ -1289,15 +1268,8 @@ def mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, Sq, q0, Sk, S_ld, H
     return att, probs
 
 
-_ATTN_BWD_NT = os.environ.get("KAI0_ATTN_BWD_NT", "1") != "0"
-_ATTN_BWD_FUSED = os.environ.get("KAI0_ATTN_BWD", "fused") != "gemm"
-_ATTN_BWD_SPLIT = os.environ.get("KAI0_ATTN_BWD_SPLIT", "auto")
-
-
 def _attn_bwd_split(Bn: int, S_ld: int, HD: int, M: int) -> int:
     """Split of the row contraction of dV = P^T dO / dK = dS^T Q so that (256x256 tiles) x batch x split fills the chip once."""
-    if _ATTN_BWD_SPLIT != "auto":
-        return int(_ATTN_BWD_SPLIT)
     t256 = ((S_ld + 255) // 256) * ((HD + 255) // 256) * Bn
     if t256 >= 160 or M < 4096:
         return 1
@@ -1337,7 +1309,7 @@ class JointAttentionFn(torch.autograd.Function):
             r0 += Li
         scale = HD**-0.5
         # one pass, no stored probabilities: the backward recomputes them from lse (kai0_attn_bwd_dq2)
-        recompute = not _ATTN_STORE_P and not _ATTN_FWD_GEMM and _ATTN_BWD_FUSED and S <= 2048
+        recompute = not _ATTN_STORE_P and S <= 2048
         att, probs = mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, S, 0, S, S_ld, H, HD, scale, want_lse=recompute)
         outs = []
         r0 = 0
@@ -1388,34 +1360,12 @@ class JointAttentionFn(torch.autograd.Function):
         dv_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
              sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0), split_k=kv_split)  # fmt: skip
-        # dS[b] [M, S_ld] = softmax'(dP), dP[b] = dO[b] [M, HD] @ V[b]^T  (V stored [S_ld][HD] = [N][K]): the softmax
-        # backward runs in the GEMM epilogue on the f32 accumulator (dP is never rounded or written; the row term
-        # <dP, P> is computed as rowsum(dO * O), kai0hip.h act 4)
         if not recompute:
             dscores = torch.empty_like(probs)
-        if recompute:
-            pass
-        elif _ATTN_BWD_FUSED:
-            # one launch: D = rowsum(dO * O), dP = dO V^T in f32, dS written once, dQ = dS K accumulated on chip
+            # stored-P form (KAI0_ATTN_STORE_P=1): one launch — D = rowsum(dO * O), dP = dO V^T in f32, dS written once, dQ = dS K on chip
             _lib.call("kai0_attn_bwd_dq", datt.data_ptr(), att.data_ptr(), probs.data_ptr(), k_all.data_ptr(), v_all.data_ptr(),
                       dscores.data_ptr(), dq_all.data_ptr(), Bn, M, S, HD, HD, HD, HD, S_ld, S_ld * H * HD, S_ld * HD, S_ld * HD,
                       M * S_ld, scale, _stream())  # fmt: skip
-        else:
-            dsum = rowdot(datt, att, HD)  # [Bn * S_ld * H]
-            gemm(datt, v_all, dscores, M=M, N=S_ld, K=HD, lda=HD, ldb=HD, ldc=S_ld, batch=Bn, sA=(S_ld * H * HD, 0),
-                 sB=(S_ld * HD, 0), sC=(M * S_ld, 0), act=4, aux1=probs, rowvec=dsum, rv=(S_ld * H, 0, 1), scale=scale)  # fmt: skip
-        # dQ[b] [M, HD] = dS[b] [M, S_ld] @ K[b] [S_ld, HD]
-        if _ATTN_BWD_FUSED or recompute:
-            pass
-        elif _ATTN_BWD_NT and S_ld % 8 == 0:
-            # through K^T (0.5 MB per sample to transpose): both operands contraction-contiguous -> the NT quadrant schedule
-            kt = torch.empty((Bn, HD, S_ld), dtype=BF16, device=dev)
-            transpose_strided(k_all, kt, R=S_ld, C=HD, src_ld=HD, dst_ld=S_ld, batch=Bn, src_bs=S_ld * HD, dst_bs=HD * S_ld)
-            gemm(dscores, kt, dq_all, M=M, N=HD, K=S_ld, lda=S_ld, ldb=S_ld, ldc=HD, batch=Bn, sA=(M * S_ld, 0),
-                 sB=(HD * S_ld, 0), sC=(S_ld * H * HD, 0))  # fmt: skip
-        else:
-            gemm(dscores, k_all, dq_all, M=M, N=HD, K=S_ld, a_kc=True, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
-                 sA=(M * S_ld, 0), sB=(S_ld * HD, 0), sC=(S_ld * H * HD, 0))  # fmt: skip
         # dK[b] [S_ld, HD] = dS[b]^T [S_ld, M] @ Q[b] [M, HD]
         dk_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(dscores, q_all, dk_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,

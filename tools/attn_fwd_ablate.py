@@ -17,4 +17,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(10): run()
 e.record(); torch.cuda.synchronize()
-print(f"ablate={os.environ.get('KAI0_ATTN_ABLATE','0'):>3s} pipe={os.environ.get('KAI0_ATTN_PIPE','1')} one-pass attention fwd: {s.elapsed_time(e) / 10:.3f} ms")
+print(f"ablate={os.environ.get('KAI0_ATTN_ABLATE','0'):>3s} one-pass attention fwd: {s.elapsed_time(e) / 10:.3f} ms")
