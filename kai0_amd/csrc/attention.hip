@@ -404,12 +404,36 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         float m_run[QT], l_run[QT];
 #pragma unroll
         for (int nt = 0; nt < QT; ++nt) { m_run[nt] = -INFINITY; l_run[nt] = 0.f; }
-        stage(0, 0, true);
+        // Key tiles in which NO key is visible to anybody (all 64 codes INT_MAX: padded prompt slots — 10-40 of pi0.5's 200 slots are
+        // filled in kai0's tasks — or the range past Sk) are skipped: the block walks the list of live tiles.  A property of the
+        // batch entry's key codes only, so the list is block-uniform; built once from the codes in LDS.
+        int* lt = kc_lds + KC_LDS_MAX;  // [0] = number of live tiles, [1 + i] = i-th live tile, [40 + t] = flag of tile t
+        const bool use_list = p.kc_lds_keys > 0;
+        int nlive = ntiles;
+        if (use_list) {
+            __syncthreads();  // the codes are in LDS
+            for (int t = wave; t < ntiles; t += WAVES) {
+                const bool any = __any(kc_lds[t * 64 + lane] != INT_MAX);
+                if (lane == 0) lt[40 + t] = any ? 1 : 0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int n = 0;
+                for (int t = 0; t < ntiles; ++t)
+                    if (lt[40 + t]) lt[1 + n++] = t;
+                lt[0] = n;
+            }
+            __syncthreads();
+            nlive = __builtin_amdgcn_readfirstlane(lt[0]);
+        }
+        auto tile_at = [&](int i) -> int { return use_list ? __builtin_amdgcn_readfirstlane(lt[1 + i]) : i; };
+        if (nlive > 0) stage(tile_at(0), 0, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        for (int kt = 0; kt < ntiles; ++kt) {
-            const int buf = NST == 2 ? (kt & 1) : 0;
-            if (NST == 2 && kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, true);
+        for (int it = 0; it < nlive; ++it) {
+            const int kt = tile_at(it);
+            const int buf = NST == 2 ? (it & 1) : 0;
+            if (NST == 2 && it + 1 < nlive && !(p.ablate & 8)) stage(tile_at(it + 1), buf ^ 1, true);
             const char* tk = smem + buf * STAGE;
             int kc[4][4];
             load_kcodes(kt, kc);
@@ -455,7 +479,7 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
             pv_tile(tk + K_BYTES, pb);
             if (NST == 1) {
                 lds_barrier();
-                if (kt + 1 < ntiles) stage(kt + 1, 0, true);
+                if (it + 1 < nlive) stage(tile_at(it + 1), 0, true);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
@@ -623,7 +647,7 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
 #define KAI0_ATTN_LAUNCH(NKS, VC, QT, OP, RB)                                                                          \
     do {                                                                                                          \
-        constexpr int LDS = (OP > 0 ? OP : (RB == 64 ? 1 : 2)) * (NKS * 8192 + 64 * VC * 2) + (RB / 32) * 4096 + KC_LDS_MAX * 4; \
+        constexpr int LDS = (OP > 0 ? OP : (RB == 64 ? 1 : 2)) * (NKS * 8192 + 64 * VC * 2) + (RB / 32) * 4096 + KC_LDS_MAX * 4 + 512; \
         static_assert(LDS <= 160 * 1024, "attention LDS budget");                                                    \
         static bool attr_set = false;                                                                             \
         auto kern = attn_fwd_kernel<NKS, VC, QT, OP, RB>;                                                             \

@@ -190,20 +190,53 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AbArgs p) {
         pn0 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(0, 0), 0, 0);
         pn1 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(0, 1), 0, 0);
     }
-    stage(0, 0);
+    // RC: key tiles in which no key is visible to anybody (all 64 codes INT_MAX: padded prompt slots) contribute nothing to dQ and
+    // have P = dS = 0: their two output slices are zero-filled here and the loop walks the live tiles only (as the forward does)
+    int* lt = kc_lds + AB_KC_MAX;  // [0] = number of live tiles, [1 + i] = i-th live tile, [40 + t] = flag of tile t
+    int nlive = ntiles;
+    if constexpr (RC) {
+        __syncthreads();  // the codes are in LDS
+        for (int t = wave; t < ntiles; t += 8) {
+            const bool any = __any(kc_lds[t * 64 + lane] != INT_MAX);
+            if (lane == 0) lt[40 + t] = any ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int t = 0; t < ntiles; ++t)
+                if (lt[40 + t]) lt[1 + n++] = t;
+            lt[0] = n;
+        }
+        __syncthreads();
+        nlive = __builtin_amdgcn_readfirstlane(lt[0]);
+        if (nlive < ntiles) {
+            const u32x4 zero = {0, 0, 0, 0};
+            for (int t = 0; t < ntiles; ++t)
+                if (!__builtin_amdgcn_readfirstlane(lt[40 + t])) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        __builtin_amdgcn_raw_buffer_store_b128(zero, po_rsrc, (int)p_off(t, hh), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(zero, ds_rsrc, (int)p_off(t, hh), 0, 0);
+                    }
+                }
+        }
+    }
+    auto tile_at = [&](int i) -> int { return RC ? __builtin_amdgcn_readfirstlane(lt[1 + i]) : i; };
+    if (nlive > 0) stage(tile_at(0), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int buf = kt & 1;
+    for (int it = 0; it < nlive; ++it) {
+        const int kt = tile_at(it);
+        const int buf = it & 1;
         const u32x4 pc[2] = {pn0, pn1};
         // next tile's P slices first, then its K / V tiles: the P loads are older than the DMA, so waiting for them later
         // never waits for the tiles
-        if (kt + 1 < ntiles) {
+        if (it + 1 < nlive) {
             if constexpr (!RC) {
                 pn0 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(kt + 1, 0), 0, 0);
                 pn1 = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)p_off(kt + 1, 1), 0, 0);
             }
-            stage(kt + 1, buf ^ 1);
+            stage(tile_at(it + 1), buf ^ 1);
         }
         const char* tv = smem + buf * STAGE;
         const char* tk = tv + VT_BYTES;
@@ -347,7 +380,7 @@ static int attn_bwd_dq_launch(const void* dO, const void* O, const void* P, cons
     hipStream_t s = (hipStream_t)stream;
 #define KAI0_AB_LAUNCH(NKS, RC)                                                                                          \
     do {                                                                                                               \
-        constexpr int LDS = 2 * (NKS * 8192 + 64 * NKS * 128) + (RC ? AB_KC_MAX * 4 : 0);                                \
+        constexpr int LDS = 2 * (NKS * 8192 + 64 * NKS * 128) + (RC ? AB_KC_MAX * 4 + 512 : 0);                                \
         static bool attr_set = false;                                                                                  \
         auto kern = attn_bwd_dq_kernel<NKS, RC>;                                                                       \
         if (!attr_set) {                                                                                               \

@@ -1276,6 +1276,27 @@ def _attn_bwd_split(Bn: int, S_ld: int, HD: int, M: int) -> int:
     return max(1, min(8, -(-256 // t256), M // 2048))
 
 
+def _joint_attention_grads(ctx, dq_all, dk_all, dv_all):
+    """The per-segment gradients out of the joint buffers: inverse RoPE while the rows are gathered (q, k), row copy (v)."""
+    q_all, k_all, v_all, probs, pos, inv_freq, att, qcode, kcode = ctx.saved_tensors
+    Bn, S, S_ld, H, HD, seg_lens, scale, recompute = ctx.cfg
+    dev = dq_all.device
+    grads = []
+    r0 = 0
+    for Li in seg_lens:
+        W3 = (H + 2) * HD  # dq | dk | dv as column slices of one [Bn*Li, W3] buffer (see fused_columns)
+        dq, dk, dv = fused_columns(Bn * Li, (H * HD, HD, HD), dev)
+        # the inverse rotation is applied while the segment's rows are gathered out of the joint gradient buffers
+        rope_copy(dq_all, dq, pos, inv_freq, Bn, Li, H, HD, src=(S_ld * H * HD, H * HD, r0), dst=(Li * W3, W3, 0), pos_bs=S,
+                  pos_off=r0, inverse=True)  # fmt: skip
+        rope_copy(dk_all, dk, pos, inv_freq, Bn, Li, 1, HD, src=(S_ld * HD, HD, r0), dst=(Li * W3, W3, 0), pos_bs=S, pos_off=r0,
+                  inverse=True)  # fmt: skip
+        _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
+        grads += [dq, dk, dv]
+        r0 += Li
+    return (None, None, None, None, None, None, None, *grads)
+
+
 class JointAttentionFn(torch.autograd.Function):
     """The shared attention of one joint layer (gemma_pytorch.py:165-219): concat the per-expert q/k/v over the
     sequence, RoPE, prefix-LM masked MQA attention, split back.
@@ -1331,8 +1352,9 @@ class JointAttentionFn(torch.autograd.Function):
         M = S * H
         dq_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
         if recompute:
-            lse, probs = probs, torch.empty((Bn, M, S_ld), dtype=BF16, device=dev)
-            dscores = torch.empty_like(probs)
+            # P and dS side by side, dV and dK likewise: the two TN GEMMs that consume them run as ONE batched launch below
+            pd = torch.empty((2, Bn, M, S_ld), dtype=BF16, device=dev)
+            lse, probs, dscores = probs, pd[0], pd[1]
         datt = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
         if S_ld > S:
             datt[:, S:].zero_()
@@ -1356,6 +1378,16 @@ class JointAttentionFn(torch.autograd.Function):
         # dV[b] [S_ld, HD] = P[b]^T [S_ld, M] @ dO[b] [M, HD]
         # (few output tiles per sample, long contraction over the M = S*H folded rows: split it so that the 256x256 ring
         # schedule gets a block per CU instead of falling back to 128x128 tiles — 578 -> ~1000 TFLOP/s)
+        if recompute and (q_all.data_ptr() - datt.data_ptr()) % 16 == 0:
+            # dV[b] = P[b]^T dO[b] and dK[b] = dS[b]^T Q[b] as one launch of 2 Bn entries: entry (j, b) reads A = pd[j][b] and
+            # B = (dO, Q)[j][b] (the two B operands are separate allocations: their distance is the outer batch stride).  256 tiles of
+            # 256 x 256 instead of 2 x 128 with a two-way split-K each: no partial products, no reduction launches
+            dkv = torch.empty((2, Bn, S_ld, HD), dtype=BF16, device=dev)
+            gemm(pd, datt, dkv, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=2 * Bn, batch_inner=Bn,
+                 sA=(Bn * M * S_ld, M * S_ld), sB=((q_all.data_ptr() - datt.data_ptr()) // 2, S_ld * H * HD),
+                 sC=(Bn * S_ld * HD, S_ld * HD), split_k=_attn_bwd_split(2 * Bn, S_ld, HD, M))  # fmt: skip
+            dv_all, dk_all = dkv[0], dkv[1]
+            return _joint_attention_grads(ctx, dq_all, dk_all, dv_all)
         kv_split = _attn_bwd_split(Bn, S_ld, HD, M)
         dv_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
@@ -1370,20 +1402,7 @@ class JointAttentionFn(torch.autograd.Function):
         dk_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(dscores, q_all, dk_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
              sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0), split_k=kv_split)  # fmt: skip
-        grads = []
-        r0 = 0
-        for Li in seg_lens:
-            W3 = (H + 2) * HD  # dq | dk | dv as column slices of one [Bn*Li, W3] buffer (see fused_columns)
-            dq, dk, dv = fused_columns(Bn * Li, (H * HD, HD, HD), dev)
-            # the inverse rotation is applied while the segment's rows are gathered out of the joint gradient buffers
-            rope_copy(dq_all, dq, pos, inv_freq, Bn, Li, H, HD, src=(S_ld * H * HD, H * HD, r0), dst=(Li * W3, W3, 0), pos_bs=S,
-                      pos_off=r0, inverse=True)  # fmt: skip
-            rope_copy(dk_all, dk, pos, inv_freq, Bn, Li, 1, HD, src=(S_ld * HD, HD, r0), dst=(Li * W3, W3, 0), pos_bs=S, pos_off=r0,
-                      inverse=True)  # fmt: skip
-            _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
-            grads += [dq, dk, dv]
-            r0 += Li
-        return (None, None, None, None, None, None, None, *grads)
+        return _joint_attention_grads(ctx, dq_all, dk_all, dv_all)
 
 
 def joint_attention(pos, qcode, kcode, inv_freq, H, HD, seg_lens, qkv):
