@@ -330,6 +330,20 @@ int kai0_layernorm_bwd(const void* dy, const void* x, const void* w, const float
 /* column sums of per-block partials (f32, `blocks` rows of stride ld, ncols columns) -> out (bf16 or f32) */
 int kai0_reduce_partials(const float* partial, int blocks, int ncols, int64_t ld, void* out, int out_f32,
                          kai0_stream_t stream);
+/* the same for n (partials, destination) pairs, 32 per launch: the training backward queues the final sums of its norm-weight
+ * and bias gradients (254 launches of ~9 us per pi0.5 step) and runs them together before the gradients are read */
+typedef struct kai0_reduce_item {
+    const float* partial; /* f32 [blocks][ld] */
+    void* out;            /* [ncols] bf16 or f32 */
+    int64_t ld;
+    int32_t blocks, ncols;
+    int32_t out_f32, _pad;
+} kai0_reduce_item;
+int kai0_reduce_partials_batch(const kai0_reduce_item* items, int n, kai0_stream_t stream);
+/* first half of kai0_colsum_bf16: per-block partial column sums into scratch [*blocks_used][N] (f32), to be summed by
+ * kai0_reduce_partials / kai0_reduce_partials_batch */
+int kai0_colsum_partials_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
+                              int* blocks_used, kai0_stream_t stream);
 /* bias gradient: out[n] = sum_m dy[m][n]  (dy bf16 [M][ld], out bf16 or f32) */
 int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
                      void* out, int out_f32, kai0_stream_t stream);
@@ -450,6 +464,19 @@ int kai0_add_f32(const float* a, const float* b, float* out, int64_t n, kai0_str
 /* dst[C][R] = src[R][C]^T (bf16, R and C multiples of 8).  Used to turn dgrad (dx = dy W) into the faster
  * K-contiguous GEMM form: W^T is 0.2 % of the bytes the GEMM streams when M = B*S is large. */
 int kai0_transpose_bf16(const void* src, void* dst, int R, int C, kai0_stream_t stream);
+/* up to 12 strided row moves in one launch: part i moves B x rows rows of `cols` bf16 elements (strides in elements),
+ * mode 0 = copy, 1 = RoPE per head of HD elements with position pos[b * pos_bs + pos_off + r], 2 = the inverse rotation,
+ * 3 = zero fill (src ignored).  The joint-attention assembly of a layer (gemma_pytorch.py:181-219: concatenate the experts'
+ * q / k / v over the sequence, rotate q and k) and its way back are one launch each. */
+typedef struct kai0_pack_part {
+    const void* src;
+    void* dst;
+    int64_t src_bs, src_ld, dst_bs, dst_ld;
+    int32_t B, rows, cols, mode;
+    int32_t pos_off, _pad;
+} kai0_pack_part;
+int kai0_pack_rows(const kai0_pack_part* parts, int n, const int32_t* pos, int64_t pos_bs, const float* inv_freq, int HD,
+                   kai0_stream_t stream);
 /* strided 2-D copy of bf16 rows: dst[b][dst_row0 + r][0:D] = src[b][src_row0 + r][0:D] */
 int kai0_copy_rows_bf16(const void* src, void* dst, int B, int rows, int D, int64_t src_bs, int64_t src_row0,
                         int64_t src_ld, int64_t dst_bs, int64_t dst_row0, int64_t dst_ld,

@@ -80,6 +80,21 @@ class SkinnySeg(C.Structure):
                 ("_pad", C.c_int32)]  # fmt: skip
 
 
+class ReduceItem(C.Structure):
+    """Mirror of `kai0_reduce_item` (include/kai0hip.h)."""
+
+    _fields_ = [("partial", c_p), ("out", c_p), ("ld", c_i64), ("blocks", C.c_int32), ("ncols", C.c_int32),
+                ("out_f32", C.c_int32), ("_pad", C.c_int32)]  # fmt: skip
+
+
+class PackPart(C.Structure):
+    """Mirror of `kai0_pack_part` (include/kai0hip.h)."""
+
+    _fields_ = [("src", c_p), ("dst", c_p), ("src_bs", c_i64), ("src_ld", c_i64), ("dst_bs", c_i64), ("dst_ld", c_i64),
+                ("B", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("mode", C.c_int32), ("pos_off", C.c_int32),
+                ("_pad", C.c_int32)]  # fmt: skip
+
+
 class SkinnyDesc(C.Structure):
     """Mirror of `kai0_skinny_desc` (include/kai0hip.h)."""
 
@@ -132,6 +147,9 @@ _PROTOS: dict[str, list] = {
     "kai0_layernorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p],
     "kai0_reduce_partials": [c_p, c_i, c_i, c_i64, c_p, c_i, c_p],
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
+    "kai0_reduce_partials_batch": [c_p, c_i, c_p],
+    "kai0_pack_rows": [c_p, c_i, c_p, c_i64, c_p, c_i, c_p],
+    "kai0_colsum_partials_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rope_inplace2": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_p],
     "kai0_rope_copy": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i, c_p],

@@ -447,6 +447,66 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
         *reinterpret_cast<bf16x8*>(d + c0) = *reinterpret_cast<const bf16x8*>(s + c0);
 }
 
+// Several strided row moves in ONE launch (the joint-attention assembly of a layer: q / k of both segments rotated into the joint
+// buffers, v copied, the padding rows cleared — 9 launches of 5-50 us otherwise; likewise the way back out).  Every part moves
+// B x rows rows of `cols` elements; mode 1 / 2 applies RoPE / its inverse per head of HD elements with the row's position
+// pos[b * pos_bs + pos_off + r], mode 3 writes zeros.  A block owns 256 / (HD/8) consecutive rows of one part: the thread layout
+// of rope_kernel (4 frequencies per thread), which for the plain copies is simply 16-B pieces strided over the row.
+struct PackArgs {
+    kai0_pack_part part[12];
+    int first[13];
+    const int32_t* pos;
+    const float* inv_freq;
+    int64_t pos_bs;
+    int n, HD;
+};
+__global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;
+    const kai0_pack_part pt = a.part[i];
+    const int HD = a.HD;
+    const int tpr = HD >> 3, rpb = 256 / tpr;
+    const int rl = threadIdx.x / tpr, tl = threadIdx.x - rl * tpr;
+    if (rl >= rpb) return;
+    const int64_t r = (int64_t)((int)blockIdx.x - a.first[i]) * rpb + rl;
+    if (r >= (int64_t)pt.B * pt.rows) return;
+    const int b = (int)(r / pt.rows), s = (int)(r - (int64_t)b * pt.rows);
+    bf16_t* yr = (bf16_t*)pt.dst + (int64_t)b * pt.dst_bs + (int64_t)s * pt.dst_ld;
+    if (pt.mode == 3) {
+        for (int c = tl * 8; c < pt.cols; c += tpr * 8) *reinterpret_cast<bf16x8*>(yr + c) = bf16x8{};
+        return;
+    }
+    const bf16_t* xr = (const bf16_t*)pt.src + (int64_t)b * pt.src_bs + (int64_t)s * pt.src_ld;
+    if (pt.mode == 0) {
+        for (int c = tl * 8; c < pt.cols; c += tpr * 8) *reinterpret_cast<bf16x8*>(yr + c) = *reinterpret_cast<const bf16x8*>(xr + c);
+        return;
+    }
+    const int i4 = tl * 4;
+    const float p = (float)a.pos[(int64_t)b * a.pos_bs + pt.pos_off + s];
+    float c[4], sn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ang = a.inv_freq[i4 + e] * p;
+        c[e] = rbf(cosf(ang));
+        sn[e] = rbf(sinf(ang));
+        if (pt.mode == 2) sn[e] = -sn[e];
+    }
+    const int H = pt.cols / HD;
+    for (int h = 0; h < H; ++h) {
+        const bf16x4 x1v = *reinterpret_cast<const bf16x4*>(xr + h * HD + i4);
+        const bf16x4 x2v = *reinterpret_cast<const bf16x4*>(xr + h * HD + i4 + (HD >> 1));
+        bf16x4 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x1 = bf2f(x1v[e]), x2 = bf2f(x2v[e]);
+            o1[e] = f2bf(rbf(x1 * c[e]) + rbf(-x2 * sn[e]));  // the roundings of rope_kernel
+            o2[e] = f2bf(rbf(x2 * c[e]) + rbf(x1 * sn[e]));
+        }
+        *reinterpret_cast<bf16x4*>(yr + h * HD + i4) = o1;
+        *reinterpret_cast<bf16x4*>(yr + h * HD + i4 + (HD >> 1)) = o2;
+    }
+}
+
 // bf16 matrix transpose through LDS: src [R][C] -> dst [C][R]; 64x64 tiles, 16-B global accesses both ways.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
                                                         int64_t src_ld, int64_t dst_ld, int64_t src_bs, int64_t dst_bs) {
@@ -734,6 +794,32 @@ KAI0_API int kai0_copy_rows_bf16(const void* src, void* dst, int B, int rows, in
     hipLaunchKernelGGL(copy_rows_kernel, dim3(B * rows), dim3(256), 0, S_(stream), (const bf16_t*)src, (bf16_t*)dst,
                        rows, D, src_bs, src_row0, src_ld, dst_bs, dst_row0, dst_ld);
     return kai0_check_launch("kai0_copy_rows_bf16");
+}
+KAI0_API int kai0_pack_rows(const kai0_pack_part* parts, int n, const int32_t* pos, int64_t pos_bs, const float* inv_freq, int HD,
+                            kai0_stream_t stream) {
+    KAI0_REQUIRE(parts != nullptr && n > 0 && n <= 12, "kai0_pack_rows: 1..12 parts (n=%d)", n);
+    KAI0_REQUIRE(HD % 8 == 0 && HD >= 8 && HD <= 2048 && 256 % (HD / 8) == 0, "kai0_pack_rows: HD=%d unsupported", HD);
+    PackArgs a;
+    const int rpb = 256 / (HD / 8);
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const kai0_pack_part& pt = parts[i];
+        KAI0_REQUIRE(pt.mode >= 0 && pt.mode <= 3 && pt.dst != nullptr && (pt.mode == 3 || pt.src != nullptr), "kai0_pack_rows: part %d", i);
+        KAI0_REQUIRE(pt.cols % 8 == 0 && pt.src_ld % 8 == 0 && pt.dst_ld % 8 == 0 && pt.src_bs % 8 == 0 && pt.dst_bs % 8 == 0 &&
+                         ((uintptr_t)pt.src % 16) == 0 && ((uintptr_t)pt.dst % 16) == 0,
+                     "kai0_pack_rows: part %d: columns / strides must be multiples of 8 elements, bases 16-byte aligned", i);
+        if (pt.mode == 1 || pt.mode == 2)
+            KAI0_REQUIRE(pos != nullptr && inv_freq != nullptr && pt.cols % HD == 0, "kai0_pack_rows: part %d rotates: positions, inv_freq, cols %% HD", i);
+        a.part[i] = pt;
+        a.first[i] = blocks;
+        const int64_t rows = (int64_t)pt.B * pt.rows;
+        blocks += rows > 0 ? (int)((rows + rpb - 1) / rpb) : 0;
+    }
+    for (int i = n; i <= 12; ++i) a.first[i] = blocks;
+    if (blocks == 0) return 0;
+    a.pos = pos; a.inv_freq = inv_freq; a.pos_bs = pos_bs; a.n = n; a.HD = HD;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, S_(stream), a);
+    return kai0_check_launch("kai0_pack_rows");
 }
 KAI0_API int kai0_transpose_bf16(const void* src, void* dst, int R, int C, kai0_stream_t stream) {
     KAI0_REQUIRE(R % 8 == 0 && C % 8 == 0, "kai0_transpose_bf16: R=%d and C=%d must be multiples of 8", R, C);

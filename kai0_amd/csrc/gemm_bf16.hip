@@ -1754,21 +1754,27 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     const bool ps_rule = p.N >= 8192 || d->K >= 8192;
     if (ps_ok && (persist == 2 || ps_rule)) {
         constexpr int LDS = 2 * 2 * 256 * 64 * 2 + 8 * 4096;  // two stages + the epilogue slabs = 160 KiB
-        static unsigned int* ctr_base = nullptr;
+        // per device: the counters' address (a __device__ symbol has one instance per device), the kernel's LDS attribute, the CU count
+        struct PsDev { unsigned int* ctr = nullptr; int cus = 0; };
+        static PsDev ps_dev[64];
         static std::atomic<unsigned> next_slot{0};
-        if (ctr_base == nullptr) {
+        int dv = 0;
+        KAI0_REQUIRE(hipGetDevice(&dv) == hipSuccess && dv >= 0 && dv < 64, "kai0_gemm_bf16: hipGetDevice");
+        PsDev& pd = ps_dev[dv];
+        if (pd.ctr == nullptr) {
             void* sym = nullptr;
             hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_ps_ctr));
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            hipDeviceProp_t pr;
+            if (e == hipSuccess) e = hipGetDeviceProperties(&pr, dv);
             KAI0_REQUIRE(e == hipSuccess, "kai0_gemm_bf16: persistent kernel setup failed: %s", hipGetErrorString(e));
-            ctr_base = (unsigned int*)sym;
+            pd.cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+            pd.ctr = (unsigned int*)sym;
         }
+        unsigned int* ctr_base = pd.ctr;
         p.tiles_m = (d->M + 255) / 256;
         p.tiles_n = (p.N + 255) / 256;
-        int ncu = 256;
-        static const int cus = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
-        ncu = cus > 0 ? cus : 256;
-        const int nblk = (int)std::min<int64_t>(big_tiles, ncu);
+        const int nblk = (int)std::min<int64_t>(big_tiles, pd.cus);
         unsigned int* ctr = ctr_base + (size_t)(next_slot.fetch_add(1) % PS_SLOTS) * 16;
         hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(nblk), dim3(512), LDS, s, p, ctr);
         return kai0_check_launch("kai0_gemm_bf16 (persistent)");

@@ -661,6 +661,34 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     }
 }
 
+// The same reduction for up to 32 (partials, destination) pairs in one launch: the final sums of the norm-weight and bias
+// gradients are ~9 us launches of 2-4 MB each (254 per training step); ops.py queues them during backward and flushes the
+// queue before anything reads the gradients.  Block b belongs to the item whose block range [first[i], first[i+1]) holds it.
+struct ReduceBatch {
+    kai0_reduce_item it[32];
+    int first[33];
+};
+__global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(ReduceBatch rb, int n) {
+    __shared__ float red[16][64];
+    int i = 0;
+    while (i + 1 < n && (int)blockIdx.x >= rb.first[i + 1]) ++i;
+    const kai0_reduce_item it = rb.it[i];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = ((int)blockIdx.x - rb.first[i]) * 64 + cl;
+    float s = 0.f;
+    if (col < it.ncols)
+        for (int b = rg; b < it.blocks; b += 16) s += it.partial[(int64_t)b * it.ld + col];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < it.ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        if (it.out_f32) reinterpret_cast<float*>(it.out)[col] = t;
+        else reinterpret_cast<bf16_t*>(it.out)[col] = f2bf(t);
+    }
+}
+
 // Column sums of a [M][N] bf16 matrix (bias gradients): block (x, y) covers the 512 columns [512 x, 512 x + 512) — one wave
 // is 64 lanes x 8 columns = 1 KiB of a row — and the rows y*4 + w, stepping by 4*gridDim.y; each wave keeps 4 independent
 // row loads in flight, the 4 waves' sums meet in LDS, and the block writes one partial row for reduce_partials.
@@ -814,16 +842,44 @@ KAI0_API int kai0_reduce_partials(const float* partial, int blocks, int ncols, i
     return kai0_check_launch("kai0_reduce_partials");
 }
 
-KAI0_API int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
-                              void* out, int out_f32, kai0_stream_t stream) {
+KAI0_API int kai0_reduce_partials_batch(const kai0_reduce_item* items, int n, kai0_stream_t stream) {
+    KAI0_REQUIRE(items != nullptr && n > 0, "kai0_reduce_partials_batch: empty");
+    for (int base = 0; base < n; base += 32) {
+        const int m = n - base < 32 ? n - base : 32;
+        ReduceBatch rb;
+        int blocks = 0;
+        for (int i = 0; i < m; ++i) {
+            rb.it[i] = items[base + i];
+            KAI0_REQUIRE(rb.it[i].partial != nullptr && rb.it[i].out != nullptr && rb.it[i].blocks > 0 && rb.it[i].ncols > 0,
+                         "kai0_reduce_partials_batch: item %d is empty", base + i);
+            rb.first[i] = blocks;
+            blocks += (rb.it[i].ncols + 63) / 64;
+        }
+        for (int i = m; i <= 32; ++i) rb.first[i] = blocks;
+        hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, rb, m);
+        int rc = kai0_check_launch("kai0_reduce_partials_batch");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+KAI0_API int kai0_colsum_partials_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
+                                       int* blocks_used, kai0_stream_t stream) {
     KAI0_REQUIRE(N % 8 == 0 && ld % 8 == 0, "kai0_colsum_bf16: N=%d and ld must be multiples of 8", N);
-    KAI0_REQUIRE(scratch_blocks > 0, "kai0_colsum_bf16: scratch_blocks must be > 0");
+    KAI0_REQUIRE(scratch_blocks > 0 && blocks_used != nullptr, "kai0_colsum_bf16: scratch_blocks must be > 0");
     int sb = scratch_blocks;
     if ((int64_t)sb > M) sb = (int)M;
     if ((int64_t)sb * 4 > M) sb = (int)((M + 3) / 4);
+    *blocks_used = sb;
     dim3 grid((N / 8 + 63) / 64, sb, 1);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, M, N, ld, scratch);
-    int rc = kai0_check_launch("kai0_colsum_bf16");
+    return kai0_check_launch("kai0_colsum_bf16");
+}
+
+KAI0_API int kai0_colsum_bf16(const void* dy, int64_t M, int N, int64_t ld, float* scratch, int scratch_blocks,
+                              void* out, int out_f32, kai0_stream_t stream) {
+    int sb = 0;
+    int rc = kai0_colsum_partials_bf16(dy, M, N, ld, scratch, scratch_blocks, &sb, stream);
     if (rc) return rc;
     return kai0_reduce_partials(scratch, sb, N, N, out, out_f32, stream);
 }

@@ -381,17 +381,18 @@ def stream_pair(device):
 def join_streams(device) -> None:
     """The current stream waits for both streams of the pair (end of a backward pass, before the optimizer / a collective)."""
     pair = stream_pair(device)
-    if pair is None:
-        return
-    cur = torch.cuda.current_stream(pair[0].device_index)
-    for st in pair:
-        if st != cur:
-            cur.wait_stream(st)
+    if pair is not None:
+        cur = torch.cuda.current_stream(pair[0].device_index)
+        for st in pair:
+            if st != cur:
+                cur.wait_stream(st)
+    flush_deferred(device.index if device.index is not None else torch.cuda.current_device())
 
 
 def reset_backward_state() -> None:
     """Start of a training step: forget a main<-side join that a previous backward pass queued but never ran (the pass raised
     before its final callbacks) — otherwise no later backward would queue the join again."""
+    _DEFERRED.clear()  # reductions an aborted backward queued: their destinations belong to that pass
     for idx in list(_JOIN_PENDING):
         if _JOIN_PENDING[idx]:
             _JOIN_PENDING[idx] = False
@@ -419,6 +420,67 @@ def _note_side_gradient(param) -> None:
         _JOIN_PENDING[idx] = True
     except RuntimeError:  # not inside a backward pass
         pair[0].wait_stream(pair[1])
+
+
+# ---------------------------------------------------------------------------------- deferred final reductions
+# The last step of every norm-weight / bias gradient is a column sum over per-block partial rows: ~9 us launches, 254 of them
+# per pi0.5 step.  When the destination is the trainer's flat gradient buffer nothing reads it before the bucket's collective or
+# the optimizer, so those sums are queued and run 32 per launch (kai0_reduce_partials_batch): flushed by join_streams (which
+# precedes every collective and the optimizer) and by a callback at the end of the backward pass.  Gradients handed back to
+# autograd as tensors are NOT deferred: AccumulateGrad may read them as soon as the node returns.
+_DEFER_REDUCE = os.environ.get("KAI0_DEFER_REDUCE", "1") != "0"
+_DEFERRED: dict = {}  # device index -> [(ReduceItem fields, tensors kept alive, producing stream)]
+
+
+def _reduce_partials(param, part, nb: int, ncols: int, ld: int, out, col0: int = 0):
+    """out[c] = sum_b part[b][col0 + c]; queued when `out` is `param`'s slice of the flat gradient buffer."""
+    src = part.data_ptr() + 4 * col0
+    f32 = int(out.dtype == F32)
+    dst = getattr(param, "_kai0_grad_out", None)
+    if not (_DEFER_REDUCE and dst is not None and out.data_ptr() == dst.data_ptr() and out.is_cuda):
+        _lib.call("kai0_reduce_partials", src, nb, ncols, ld, out.data_ptr(), f32, _stream())
+        return
+    idx = out.device.index
+    q = _DEFERRED.setdefault(idx, [])
+    q.append(((src, out.data_ptr(), ld, nb, ncols, f32, 0), (part, out), torch.cuda.current_stream(idx)))
+    if len(q) == 1:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred(idx))
+        except RuntimeError:  # not inside a backward pass
+            flush_deferred(idx)
+
+
+def flush_deferred(idx=None) -> None:
+    """Run the queued reductions of device `idx` (all devices if None) on the current stream, behind their producers."""
+    for i in list(_DEFERRED) if idx is None else [idx]:
+        q = _DEFERRED.get(i)
+        if not q:
+            continue
+        _DEFERRED[i] = []
+        cur = torch.cuda.current_stream(i)
+        for st in {e[2] for e in q}:
+            if st != cur:
+                cur.wait_stream(st)
+        items = (_lib.ReduceItem * len(q))(*[_lib.ReduceItem(*e[0]) for e in q])
+        with torch.cuda.device(i):
+            _lib.call("kai0_reduce_partials_batch", C.addressof(items), len(q), cur.cuda_stream)
+        for e in q:  # partial buffers allocated under another stream: not to be reused before this launch has read them
+            if e[2] != cur:
+                e[1][0].record_stream(cur)
+
+
+def _bias_grads(dy, M: int, N: int, ld: int, biases):
+    """Column sums of dy [M, N] (row stride ld) into the gradients of `biases` = [(bias, first column, width)]: one pass over dy
+    into per-block partials, then one (queued) final sum per bias.  Returns what the backward hands to autograd per bias."""
+    scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=dy.device)
+    used = C.c_int(0)
+    _lib.call("kai0_colsum_partials_bf16", dy.data_ptr(), M, N, ld, scratch.data_ptr(), COLSUM_BLOCKS, C.addressof(used), _stream())
+    out = []
+    for b, c0, width in biases:
+        db = _grad_dst(b, b.dtype)
+        _reduce_partials(b, scratch, used.value, width, N, db, col0=c0)
+        out.append(_grad_ret(b, db))
+    return out
 
 
 # ----------------------------------------------------------------------------------------- autograd shims
@@ -470,11 +532,8 @@ class LinearFn(torch.autograd.Function):
             # dw[N,K] = dy[M,N]^T @ x[M,K]  (both stored [contraction][cols])
             gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M), nt_out=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _grad_dst(ctx.bias, ctx.bias_dtype)
-            scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=x.device)
-            _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, N, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
-                      int(ctx.bias_dtype == F32), _stream())  # fmt: skip
-        return dx, _grad_ret(w, dw), _grad_ret(ctx.bias, db), dres, None
+            (db,) = _bias_grads(dy, M, N, N, [(ctx.bias, 0, N)])
+        return dx, _grad_ret(w, dw), db, dres, None
 
 
 def transpose(x: torch.Tensor) -> torch.Tensor:
@@ -589,17 +648,8 @@ class LinearMultiFn(torch.autograd.Function):
                 r += widths[i]
                 dws[i] = _grad_ret(w, dst)
         if bs[0] is not None and any(ctx.needs_input_grad[2 + n + i] for i in range(n)):
-            f32 = bs[0].dtype == F32
-            dbcat = torch.empty((Nt,), dtype=bs[0].dtype, device=dev)
-            scratch = torch.empty((COLSUM_BLOCKS, Nt), dtype=F32, device=dev)
-            _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, Nt, Nt, scratch.data_ptr(), COLSUM_BLOCKS, dbcat.data_ptr(), int(f32),
-                      _stream())  # fmt: skip
-            r = 0
-            for i, b in enumerate(bs):
-                db = _grad_dst(b, b.dtype)
-                db.copy_(dbcat[r : r + widths[i]])
-                r += widths[i]
-                dbs[i] = _grad_ret(b, db)
+            offs = [sum(widths[:i]) for i in range(n)]
+            dbs = _bias_grads(dy, M, Nt, Nt, [(b, offs[i], widths[i]) for i, b in enumerate(bs)])
         return (dx, None, *dws, *dbs)
 
     @staticmethod
@@ -628,11 +678,7 @@ class LinearMultiFn(torch.autograd.Function):
                 gemm(dy, x, dw, M=N, N=K, K=M, a_kc=False, b_kc=False, lda=N, ldb=K, ldc=K, split_k=pick_split_k_wgrad(N, K, M), nt_out=True)
                 dws[i] = _grad_ret(w, dw)
             if b is not None and ctx.needs_input_grad[2 + n + i]:
-                db = _grad_dst(b, b.dtype)
-                scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=dev)
-                _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, N, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
-                          int(b.dtype == F32), _stream())  # fmt: skip
-                dbs[i] = _grad_ret(b, db)
+                (dbs[i],) = _bias_grads(dy, M, N, N, [(b, 0, N)])
         if dx is not None and first:
             dx.zero_()
         return (dx, None, *dws, *dbs)
@@ -730,7 +776,7 @@ class RMSNormFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _grad_dst(w, F32)
-            _lib.call("kai0_reduce_partials", part.data_ptr(), nb, D, D, dw.data_ptr(), 1, _stream())
+            _reduce_partials(w, part, nb, D, D, dw)
         return dx, _grad_ret(w, dw), None
 
 
@@ -817,9 +863,8 @@ class LayerNormFn(torch.autograd.Function):
         _lib.call("kai0_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                   dx.data_ptr(), part.data_ptr(), nb, _p(dres), rows, D, _stream())  # fmt: skip
         dw, db = _grad_dst(w, w.dtype), _grad_dst(b, b.dtype)
-        f32 = int(w.dtype == F32)
-        _lib.call("kai0_reduce_partials", part.data_ptr(), nb, D, 2 * D, dw.data_ptr(), f32, _stream())
-        _lib.call("kai0_reduce_partials", part.data_ptr() + 4 * D, nb, D, 2 * D, db.data_ptr(), f32, _stream())
+        _reduce_partials(w, part, nb, D, 2 * D, dw)
+        _reduce_partials(b, part, nb, D, 2 * D, db, col0=D)
         return dx, _grad_ret(w, dw), _grad_ret(b, db), None
 
 
@@ -962,11 +1007,7 @@ class GeluMlpFn(torch.autograd.Function):
         big = M >= 4096
 
         def colsum(dy, N, ld, b):
-            db = _grad_dst(b, b.dtype)
-            scratch = torch.empty((COLSUM_BLOCKS, N), dtype=F32, device=dev)
-            _lib.call("kai0_colsum_bf16", dy.data_ptr(), M, N, ld, scratch.data_ptr(), COLSUM_BLOCKS, db.data_ptr(),
-                      int(b.dtype == F32), _stream())  # fmt: skip
-            return _grad_ret(b, db)
+            return _bias_grads(dy, M, N, ld, [(b, 0, N)])[0]
 
         dw2 = db2 = dw1 = db1 = dx = None
         if ctx.needs_input_grad[3]:
@@ -1211,6 +1252,21 @@ def rope_copy(src_t, dst_t, pos, inv_freq, Bn, S, H, HD, *, src, dst, pos_bs, po
               inv_freq.data_ptr(), Bn, S, H, HD, sbs, sld, dbs, dld, pos_bs, int(inverse), _stream())  # fmt: skip
 
 
+def pack_rows(parts, HD: int, pos=None, pos_bs: int = 0, inv_freq=None):
+    """kai0_pack_rows: up to 12 strided row moves in one launch.  parts = [(src | None, src element offset, dst, dst element offset,
+    (src batch stride, src row stride), (dst batch stride, dst row stride), B, rows, cols, mode, pos_off)] with mode 0 copy,
+    1 RoPE, 2 inverse RoPE, 3 zero fill."""
+    for c0 in range(0, len(parts), 12):
+        chunk = parts[c0 : c0 + 12]
+        arr = (_lib.PackPart * len(chunk))()
+        for a, (src, soff, dst, doff, (sbs, sld), (dbs, dld), Bn, rows, cols, mode, pos_off) in zip(arr, chunk):
+            a.src = None if src is None else src.data_ptr() + 2 * soff
+            a.dst = dst.data_ptr() + 2 * doff
+            a.src_bs, a.src_ld, a.dst_bs, a.dst_ld = sbs, sld, dbs, dld
+            a.B, a.rows, a.cols, a.mode, a.pos_off = Bn, rows, cols, mode, pos_off
+        _lib.call("kai0_pack_rows", C.addressof(arr), len(chunk), _p(pos), pos_bs, _p(inv_freq), HD, _stream())
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -1276,24 +1332,23 @@ def _attn_bwd_split(Bn: int, S_ld: int, HD: int, M: int) -> int:
     return max(1, min(8, -(-256 // t256), M // 2048))
 
 
-def _joint_attention_grads(ctx, dq_all, dk_all, dv_all):
-    """The per-segment gradients out of the joint buffers: inverse RoPE while the rows are gathered (q, k), row copy (v)."""
-    q_all, k_all, v_all, probs, pos, inv_freq, att, qcode, kcode = ctx.saved_tensors
-    Bn, S, S_ld, H, HD, seg_lens, scale, recompute = ctx.cfg
+def _joint_attention_grads(cfg, pos, inv_freq, dq_all, dk_all, dv_all):
+    """The per-segment gradients out of the joint buffers: inverse RoPE while the rows are gathered (q, k), row copy (v).
+    (Takes what it needs of the saved tensors from the caller: under activation checkpointing they can be unpacked once only.)"""
+    Bn, S, S_ld, H, HD, seg_lens, scale, recompute = cfg
     dev = dq_all.device
-    grads = []
+    grads, parts = [], []
     r0 = 0
     for Li in seg_lens:
         W3 = (H + 2) * HD  # dq | dk | dv as column slices of one [Bn*Li, W3] buffer (see fused_columns)
         dq, dk, dv = fused_columns(Bn * Li, (H * HD, HD, HD), dev)
         # the inverse rotation is applied while the segment's rows are gathered out of the joint gradient buffers
-        rope_copy(dq_all, dq, pos, inv_freq, Bn, Li, H, HD, src=(S_ld * H * HD, H * HD, r0), dst=(Li * W3, W3, 0), pos_bs=S,
-                  pos_off=r0, inverse=True)  # fmt: skip
-        rope_copy(dk_all, dk, pos, inv_freq, Bn, Li, 1, HD, src=(S_ld * HD, HD, r0), dst=(Li * W3, W3, 0), pos_bs=S, pos_off=r0,
-                  inverse=True)  # fmt: skip
-        _copy_rows(dv_all, dv, Bn, Li, HD, S_ld * HD, r0, HD, Li * W3, 0, W3)
+        parts.append((dq_all, r0 * H * HD, dq, 0, (S_ld * H * HD, H * HD), (Li * W3, W3), Bn, Li, H * HD, 2, r0))
+        parts.append((dk_all, r0 * HD, dk, 0, (dk_all.stride(0), HD), (Li * W3, W3), Bn, Li, HD, 2, r0))
+        parts.append((dv_all, r0 * HD, dv, 0, (dv_all.stride(0), HD), (Li * W3, W3), Bn, Li, HD, 0, 0))
         grads += [dq, dk, dv]
         r0 += Li
+    pack_rows(parts, HD, pos, S, inv_freq)
     return (None, None, None, None, None, None, None, *grads)
 
 
@@ -1315,31 +1370,34 @@ class JointAttentionFn(torch.autograd.Function):
         q_all = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
         k_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         v_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
-        if S_ld > S:  # only the padding rows need defined (zero) contents: they enter dK/dV GEMMs multiplied by P = 0
-            q_all[:, S:].zero_()
-            k_all[:, S:].zero_()
-            v_all[:, S:].zero_()
+        # one launch: q / k of every segment rotated on their way into the joint buffers, v copied, and the padding rows cleared
+        # (only they need defined contents: they enter the dK / dV GEMMs multiplied by P = 0)
+        parts = []
         r0 = 0
         for i in range(nseg):
             Li = seg_lens[i]
-            # q / k are rotated on their way into the joint buffers (one pass instead of copy + in-place RoPE)
-            rope_copy(qs[i], q_all, pos, inv_freq, Bn, Li, H, HD, src=(Li * H * HD, H * HD, 0), dst=(S_ld * H * HD, H * HD, r0),
-                      pos_bs=S, pos_off=r0)  # fmt: skip
-            rope_copy(ks[i], k_all, pos, inv_freq, Bn, Li, 1, HD, src=(Li * HD, HD, 0), dst=(S_ld * HD, HD, r0), pos_bs=S, pos_off=r0)
-            _copy_rows(vs[i], v_all, Bn, Li, HD, Li * HD, 0, HD, S_ld * HD, r0, HD)
+            parts.append((qs[i], 0, q_all, r0 * H * HD, (Li * qs[i].stride(0), qs[i].stride(0)), (S_ld * H * HD, H * HD), Bn, Li, H * HD, 1, r0))
+            parts.append((ks[i], 0, k_all, r0 * HD, (Li * ks[i].stride(0), ks[i].stride(0)), (S_ld * HD, HD), Bn, Li, HD, 1, r0))
+            parts.append((vs[i], 0, v_all, r0 * HD, (Li * vs[i].stride(0), vs[i].stride(0)), (S_ld * HD, HD), Bn, Li, HD, 0, 0))
             r0 += Li
+        if S_ld > S:
+            parts.append((None, 0, q_all, S * H * HD, (0, 0), (S_ld * H * HD, H * HD), Bn, S_ld - S, H * HD, 3, 0))
+            parts.append((None, 0, k_all, S * HD, (0, 0), (S_ld * HD, HD), Bn, S_ld - S, HD, 3, 0))
+            parts.append((None, 0, v_all, S * HD, (0, 0), (S_ld * HD, HD), Bn, S_ld - S, HD, 3, 0))
+        pack_rows(parts, HD, pos, S, inv_freq)
         scale = HD**-0.5
         # one pass, no stored probabilities: the backward recomputes them from lse (kai0_attn_bwd_dq2)
         recompute = not _ATTN_STORE_P and S <= 2048
         att, probs = mqa_attention_fwd(q_all, k_all, v_all, qcode, kcode, Bn, S, 0, S, S_ld, H, HD, scale, want_lse=recompute)
-        outs = []
+        outs, parts = [], []
         r0 = 0
         for i in range(nseg):
             Li = seg_lens[i]
             o = torch.empty((Bn * Li, H * HD), dtype=BF16, device=dev)
-            _copy_rows(att, o, Bn, Li, H * HD, S_ld * H * HD, r0, H * HD, Li * H * HD, 0, H * HD)
+            parts.append((att, r0 * H * HD, o, 0, (S_ld * H * HD, H * HD), (Li * H * HD, H * HD), Bn, Li, H * HD, 0, 0))
             outs.append(o)
             r0 += Li
+        pack_rows(parts, HD)
         ctx.save_for_backward(q_all, k_all, v_all, probs, pos, inv_freq, att, qcode, kcode)
         ctx.cfg = (Bn, S, S_ld, H, HD, seg_lens, scale, recompute)
         return tuple(outs)
@@ -1356,12 +1414,14 @@ class JointAttentionFn(torch.autograd.Function):
             pd = torch.empty((2, Bn, M, S_ld), dtype=BF16, device=dev)
             lse, probs, dscores = probs, pd[0], pd[1]
         datt = torch.empty((Bn, S_ld, H * HD), dtype=BF16, device=dev)
-        if S_ld > S:
-            datt[:, S:].zero_()
+        parts = []
         r0 = 0
         for i, Li in enumerate(seg_lens):
-            _copy_rows(douts[i].contiguous(), datt, Bn, Li, H * HD, Li * H * HD, 0, H * HD, S_ld * H * HD, r0, H * HD)
+            parts.append((douts[i].contiguous(), 0, datt, r0 * H * HD, (Li * H * HD, H * HD), (S_ld * H * HD, H * HD), Bn, Li, H * HD, 0, 0))
             r0 += Li
+        if S_ld > S:
+            parts.append((None, 0, datt, S * H * HD, (0, 0), (S_ld * H * HD, H * HD), Bn, S_ld - S, H * HD, 3, 0))
+        pack_rows(parts, HD)
         if recompute:
             # query side first: it (re)produces P for the dV GEMM below — S, P = exp(S - lse), dP, dS, dQ in one launch
             d = AttnBwdDesc()
@@ -1387,7 +1447,7 @@ class JointAttentionFn(torch.autograd.Function):
                  sA=(Bn * M * S_ld, M * S_ld), sB=((q_all.data_ptr() - datt.data_ptr()) // 2, S_ld * H * HD),
                  sC=(Bn * S_ld * HD, S_ld * HD), split_k=_attn_bwd_split(2 * Bn, S_ld, HD, M))  # fmt: skip
             dv_all, dk_all = dkv[0], dkv[1]
-            return _joint_attention_grads(ctx, dq_all, dk_all, dv_all)
+            return _joint_attention_grads(ctx.cfg, pos, inv_freq, dq_all, dk_all, dv_all)
         kv_split = _attn_bwd_split(Bn, S_ld, HD, M)
         dv_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(probs, datt, dv_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
@@ -1402,7 +1462,7 @@ class JointAttentionFn(torch.autograd.Function):
         dk_all = torch.empty((Bn, S_ld, HD), dtype=BF16, device=dev)
         gemm(dscores, q_all, dk_all, M=S_ld, N=HD, K=M, a_kc=False, b_kc=False, lda=S_ld, ldb=HD, ldc=HD, batch=Bn,
              sA=(M * S_ld, 0), sB=(S_ld * H * HD, 0), sC=(S_ld * HD, 0), split_k=kv_split)  # fmt: skip
-        return _joint_attention_grads(ctx, dq_all, dk_all, dv_all)
+        return _joint_attention_grads(ctx.cfg, pos, inv_freq, dq_all, dk_all, dv_all)
 
 
 def joint_attention(pos, qcode, kcode, inv_freq, H, HD, seg_lens, qkv):

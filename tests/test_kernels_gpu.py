@@ -284,6 +284,43 @@ def test_layernorm_fwd_bwd(ops, rows, D):
     assert rel_err(w.grad, wr.grad) < 1e-2 and rel_err(b.grad, br.grad) < 1e-2
 
 
+def test_queued_final_reductions_equal_the_immediate_ones(ops):
+    """Norm-weight / bias gradients whose destination is a trainer's flat buffer (`_kai0_grad_out`) are summed by the batched
+    launch at the end of the backward pass: the same bits as the per-gradient launches, also past 32 queued items."""
+    rows, D = 700, 1152
+
+    def run(flat):
+        torch.manual_seed(0)
+        x = rnd(rows, D, seed=1).requires_grad_(True)
+        lns = [((1 + rnd(D, seed=10 + i, scale=0.2).float()).to(BF16).requires_grad_(True), rnd(D, seed=40 + i, scale=0.2).requires_grad_(True))
+               for i in range(14)]  # 28 LayerNorm items
+        rw = [rnd(D, dtype=F32, seed=70 + i, scale=0.3).requires_grad_(True) for i in range(4)]
+        ws = [rnd(n, D, seed=80 + i, scale=0.1).requires_grad_(True) for i, n in enumerate((136, 72, 72))]
+        bs = [rnd(n, seed=90 + i).requires_grad_(True) for i, n in enumerate((136, 72, 72))]
+        params = [t for pair in lns for t in pair] + rw + bs
+        arrived = []
+        if flat:
+            for p_ in params:
+                p_._kai0_grad_out = torch.full_like(p_, float("nan"))
+                p_._kai0_grad_done = lambda p_=p_: arrived.append(p_)
+        h = x
+        for w, b in lns:
+            h = ops.layernorm(h, w, b, 1e-6)
+        for w in rw:
+            h = ops.rmsnorm(h, w, 1e-6)
+        q, k, v = ops.linear_multi(h, ws, bs)
+        torch.autograd.backward([q, k, v], [rnd(rows, 136, seed=11), rnd(rows, 72, seed=12), rnd(rows, 72, seed=13)])
+        if flat:
+            assert len(arrived) == len(params) and all(p_.grad is None for p_ in params)
+            return [p_._kai0_grad_out for p_ in params] + [x.grad]
+        return [p_.grad for p_ in params] + [x.grad]
+
+    ref, got = run(False), run(True)
+    assert not ops._DEFERRED.get(torch.cuda.current_device())
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
 def test_norm_residual_passthrough_and_linear_multi(ops):
     """x feeds a norm AND a residual: one backward kernel returns dres + dnorm; q/k/v dgrads accumulate in the epilogue."""
     rows, D = 300, 136
