@@ -599,7 +599,10 @@ class LinearMultiFn(torch.autograd.Function):
             return outs
         M, K = x.shape
         Nt = sum(widths)
-        wcat = torch.cat(ws, dim=0)
+        # (a trainer's flat parameter buffer holds q / k / v back to back: the stacked weight is then a view, not a copy)
+        wcat = _as_rows([w.detach() for w in ws])
+        if wcat is None:
+            wcat = torch.cat(ws, dim=0)
         bcat = torch.cat(bs, dim=0) if all(has_b) else None
         outs = tuple(torch.empty((M, w), dtype=BF16, device=x.device) for w in widths)
         segs, c = [], 0

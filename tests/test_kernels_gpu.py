@@ -1265,6 +1265,53 @@ def test_denoise_glue_equals_the_six_launches_it_replaces(ops, B, Hs):
     assert torch.equal(x_o, x_ref) and rel_err(xs_o, xs_ref) < 2e-3
 
 
+@pytest.mark.parametrize("HD,H", [(256, 8), (64, 2)])
+def test_pack_rows_equals_the_separate_rope_copy_and_fill_launches(ops, HD, H):
+    """kai0_pack_rows (a layer's joint-attention assembly in one launch: two segments' q / k rotated into the joint buffers, v copied,
+    padding rows cleared, and the inverse rotation on the way back into column slices) == kai0_rope_copy / kai0_copy_rows, bit for bit."""
+    B, lens = 3, (37, 5)
+    S = sum(lens)
+    S_ld = S + 6
+    pos = torch.randint(0, 900, (B, S), dtype=torch.int32, device=dev())
+    inv = (1.0 / (10000.0 ** (torch.arange(0, HD, 2, dtype=torch.float32) / HD))).to(dev())
+    qs = [rnd(B * L, H * HD, seed=10 + i) for i, L in enumerate(lens)]
+    ks = [rnd(B * L, HD, seed=20 + i) for i, L in enumerate(lens)]
+    vs = [rnd(B * L, HD, seed=30 + i) for i, L in enumerate(lens)]
+    nan = float("nan")
+    ref = [torch.full((B, S_ld, w), nan, dtype=BF16, device=dev()) for w in (H * HD, HD, HD)]
+    got = [t.clone() for t in ref]
+    for t in ref:
+        t[:, S:].zero_()
+    parts, r0 = [], 0
+    for i, L in enumerate(lens):
+        ops.rope_copy(qs[i], ref[0], pos, inv, B, L, H, HD, src=(L * H * HD, H * HD, 0), dst=(S_ld * H * HD, H * HD, r0), pos_bs=S, pos_off=r0)
+        ops.rope_copy(ks[i], ref[1], pos, inv, B, L, 1, HD, src=(L * HD, HD, 0), dst=(S_ld * HD, HD, r0), pos_bs=S, pos_off=r0)
+        ops._copy_rows(vs[i], ref[2], B, L, HD, L * HD, 0, HD, S_ld * HD, r0, HD)
+        parts.append((qs[i], 0, got[0], r0 * H * HD, (L * H * HD, H * HD), (S_ld * H * HD, H * HD), B, L, H * HD, 1, r0))
+        parts.append((ks[i], 0, got[1], r0 * HD, (L * HD, HD), (S_ld * HD, HD), B, L, HD, 1, r0))
+        parts.append((vs[i], 0, got[2], r0 * HD, (L * HD, HD), (S_ld * HD, HD), B, L, HD, 0, 0))
+        r0 += L
+    for t, w in zip(got, (H * HD, HD, HD)):
+        parts.append((None, 0, t, S * w, (0, 0), (S_ld * w, w), B, S_ld - S, w, 3, 0))
+    ops.pack_rows(parts, HD, pos, S, inv)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # the way back: inverse rotation while a segment's rows are gathered into column slices of one buffer
+    W3 = (H + 2) * HD
+    r0 = lens[0]
+    L = lens[1]
+    ref_b = torch.full((B * L, W3), nan, dtype=BF16, device=dev())
+    got_b = ref_b.clone()
+    ops.rope_copy(ref[0], ref_b, pos, inv, B, L, H, HD, src=(S_ld * H * HD, H * HD, r0), dst=(L * W3, W3, 0), pos_bs=S, pos_off=r0, inverse=True)
+    ops.rope_copy(ref[1], ref_b[:, H * HD :], pos, inv, B, L, 1, HD, src=(S_ld * HD, HD, r0), dst=(L * W3, W3, 0), pos_bs=S, pos_off=r0,
+                  inverse=True)
+    ops._copy_rows(ref[2], ref_b[:, (H + 1) * HD :], B, L, HD, S_ld * HD, r0, HD, L * W3, 0, W3)
+    ops.pack_rows([(got[0], r0 * H * HD, got_b, 0, (S_ld * H * HD, H * HD), (L * W3, W3), B, L, H * HD, 2, r0),
+                   (got[1], r0 * HD, got_b[:, H * HD :], 0, (S_ld * HD, HD), (L * W3, W3), B, L, HD, 2, r0),
+                   (got[2], r0 * HD, got_b[:, (H + 1) * HD :], 0, (S_ld * HD, HD), (L * W3, W3), B, L, HD, 0, 0)], HD, pos, S, inv)
+    assert torch.equal(ref_b, got_b)
+
+
 def test_rope_two_tensors_in_one_launch(ops):
     """kai0_rope_inplace2 (q and k of a layer, shared positions) == two kai0_rope_inplace calls, bit for bit."""
     B, S, S_ld, H, HD = 2, 37, 40, 8, 256
