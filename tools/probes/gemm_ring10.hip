@@ -252,7 +252,8 @@ static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main() {
-    const int shapes[][3] = {{30976, 2048, 16384}, {30976, 16384, 2048}, {30976, 2048, 2048}, {8192, 8192, 8192}};
+    const int shapes[][3] = {{30976, 2048, 16384}, {30976, 16384, 2048}, {30976, 2048, 2048}, {8192, 8192, 8192},
+                             {24576, 4352, 1152}, {24576, 3584, 1152}, {24576, 1280, 1152}, {24576, 1280, 4352}, {30976, 2560, 2048}};  // (SigLIP-like: N, K padded to the probe's multiples)
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
         std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
