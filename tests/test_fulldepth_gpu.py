@@ -67,7 +67,7 @@ def fd():
             f"{pe.exp_cfg.width}/{pe.exp_cfg.mlp_dim} + {pe.siglip_cfg.hidden_size}/{pe.siglip_cfg.intermediate_size}; "
             f"prompt valid tokens {int(obs.tokenized_prompt_mask.sum())} of {obs.tokenized_prompt.shape[1]}; "
             f"host threads {torch.get_num_threads()}; build {time.time() - t0:.1f} s")  # fmt: skip
-    return dict(model=model, o32=o32, obf=obf, obs=obs, gobs=obs_to(obs, dev), actions=actions, noise=noise, time=tm, dev=dev)
+    return dict(model=model, o32=o32, obf=obf, ocfg=ocfg, obs=obs, gobs=obs_to(obs, dev), actions=actions, noise=noise, time=tm, dev=dev)
 
 
 def test_fulldepth_is_the_baseline_architecture(fd):
@@ -174,6 +174,44 @@ def test_fulldepth_action_chunk_matches_oracle(fd):
         assert torch.equal(out, m.sample_actions(d, fd["gobs"], noise=fd["noise"].to(d), num_steps=10))  # replay is deterministic
     finally:
         m.train()
+
+
+def test_fulldepth_second_case_short_ragged_prompts_masked_camera(fd):
+    """A second full-depth case (one seed, B = 1, one prompt length): another seed, B = 2, the 17 / 41-token prompts
+    kai0's tasks have (whole key tiles of padding: the attention kernels' dead-tile skip), and sample 1's right-wrist camera masked out
+    (256 hidden keys in the middle of the prefix).  Loss tensor and 10-step chunk against the fp32 oracle, BASELINE.md section 4 tolerances."""
+    from tiny import obs_to
+
+    from oracle.pi0_oracle import synthetic_batch
+
+    m, o32, d = fd["model"], fd["o32"], fd["dev"]
+    obs, actions, noise, tm = synthetic_batch(fd["ocfg"], 2, seed=9)
+    L = obs.tokenized_prompt.shape[1]
+    obs.tokenized_prompt_mask = torch.arange(L)[None, :] < torch.tensor([17, 41])[:, None]
+    last = list(obs.image_masks)[-1]
+    obs.image_masks[last] = torch.tensor([True, False])
+    gobs = obs_to(obs, d)
+    with torch.no_grad():
+        loss = m(gobs, actions.to(d), noise=noise.to(d), time=tm.to(d))
+        t0 = time.time()
+        ref = o32(obs, actions, noise, tm)
+        t_l = time.time() - t0
+    r_l = rel(loss, ref)
+    m.eval()
+    try:
+        out = m.sample_actions(d, gobs, noise=noise.to(d), num_steps=10)
+        t0 = time.time()
+        with torch.no_grad():
+            refc = o32.sample_actions(obs, noise, num_steps=10)
+        t_c = time.time() - t0
+    finally:
+        m.train()
+    r_c, mx = rel(out, refc), float((out.cpu() - refc).abs().max())
+    per = [rel(out[i], refc[i]) for i in range(2)]
+    _report(f"second case (seed 9, B = 2, prompts of 17 / 41 valid tokens, sample 1 without its third camera): loss [2,50,32] rel-L2 {r_l:.3e} "
+            f"(oracle {t_l:.1f} s); 10-step chunk rel-L2 {r_c:.3e} (per sample {per[0]:.3e} / {per[1]:.3e}), max|d| {mx:.3e} vs fp32 oracle ({t_c:.1f} s)")  # fmt: skip
+    assert loss.shape == (2, 50, 32) and r_l <= 1e-2
+    assert r_c <= 1e-2 and mx <= 2e-2 and max(per) <= 1e-2
 
 
 def test_fulldepth_advantage_estimator_matches_oracle(fd):
