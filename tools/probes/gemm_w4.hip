@@ -148,6 +148,131 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(const bf16_t* __restrict__ A, 
     }
 }
 
+// The transpose-read form (weight gradients): C[M][N] = A^T B with A stored [K][M], B stored [K][N].  LDS image of an operand tile
+// = [64 k-rows][256 columns] (512-B rows), 2 k-rows per DMA piece, 16-B slot s of row r holding source chunk s ^ (key(r) << 1),
+// key(r) = (r & 3) | (((r >> 3) & 1) << 2); fragments by ds_read_b64_tr_b16 (two per 16 x 32 operand), as in the production kernel.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+__global__ __launch_bounds__(256, 1) void gemm_w4_tn(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M,
+                                                     int N, int K, int tiles_m, int tiles_n) {
+    constexpr int TM = 256, TN = 256, NJ = 8, A_TILE = 64 * 512, STAGE = 2 * A_TILE, NP = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = pid & 7, idx = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP = 4;
+    const int width = GROUP * tiles_n, group = pid / width, first_m = group * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP), in_g = pid - group * width;
+    const int m0 = (first_m + in_g % gsz) * TM, n0 = (in_g / gsz) * TN;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    const int nk = K / BK;
+    // piece q: pieces [0, 32) = A k-rows 2q, 2q+1; [32, 64) = B k-rows; wave w issues pieces 16 w .. 16 w + 15
+    // (offsets recomputed per piece — a handful of VALU ops — rather than held in 16 registers: with them hipcc started rotating
+    // accumulators between AGPRs and VGPRs, 300 v_accvgpr moves per K-tile)
+    auto piece_voff = [&](int j) -> uint32_t {
+        const int q = wave * NP + j;
+        const bool isa = q < 32;
+        const int r = (q & 31) * 2 + (lane >> 5);
+        const int key = (r & 3) | (((r >> 3) & 1) << 2);
+        const int col = (isa ? m0 : n0) + (((lane & 31) ^ (key << 1)) * 8);
+        return (uint32_t)col * 2 + (uint32_t)r * (uint32_t)(isa ? M : N) * 2;
+    };
+    const int sa_k = BK * M * 2, sb_k = BK * N * 2;  // byte advance per K-tile (soffset)
+    auto issue = [&](int j, int t, int slot) {
+        const int q = wave * NP + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < 32 ? a_rsrc : b_rsrc, (LDS_PTR(void))(smem + slot * STAGE + q * 1024), 16, (int)piece_voff(j),
+                                                  t * (q < 32 ? sa_k : sb_k), 0, 0);
+    };
+    // fragment addresses: operand column group c (16 columns) of the wave's 128: chunk = 16 w + 2 c + b, b = (l15 & 3) >> 1;
+    // (2 c + b) ^ (key << 1) = 2 (c ^ key) + b with key = (l15 >> 2) | ((g & 1) << 2); k-row r0 = 32 ks + 8 g + (l15 >> 2), second read r0 + 4
+    const int keyv = (l15 >> 2) | ((g & 1) << 2), bb = (l15 & 3) >> 1;
+    int adA[8], adB[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int row_part = (8 * g + (l15 >> 2)) * 512 + (l15 & 1) * 8;
+        adA[c] = row_part + ((wm * 16 + 2 * (c ^ keyv) + bb) << 4);
+        adB[c] = A_TILE + row_part + ((wn * 16 + 2 * (c ^ keyv) + bb) << 4);
+    }
+    auto frag = [&](int slot, int ad, int ks) -> bf16x8 {
+        const char* b = smem + slot * STAGE + ad + ks * 16384;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(b));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(b + 2048));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue(j, min(1, nk - 1), 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a0[i] = frag(0, adA[i], 0);
+        b0[i] = frag(0, adB[i], 0);
+    }
+    for (int t = 0; t < nk; ++t) {
+        const int slot = t & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a1[i] = frag(slot, adA[i], 1);
+            b1[i] = frag(slot, adB[i], 1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int tn = min(t + 2, nk - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            issue(2 * i, tn, slot);
+            issue(2 * i + 1, tn, slot);
+            a0[i] = frag(slot ^ 1, adA[i], 0);
+            b0[i] = frag(slot ^ 1, adB[i], 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem + wave * (16 * 128 * 4));
+    constexpr int WC = 128;
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(4 * g + r) * WC + j * 16 + l15] = acc[ti][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < 16 * WC / 8; idx += 64) {
+            const int r = idx / (WC / 8), c8 = (idx % (WC / 8)) * 8;
+            const float* sp = slab + r * WC + c8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)sp[e];
+            const int row = m0 + wm * 128 + ti * 16 + r, col = n0 + wn * WC + c8;
+            *reinterpret_cast<bf16x8*>(C + (int64_t)row * N + col) = o;
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 
@@ -209,6 +334,56 @@ int main() {
         CK(hipGetLastError());
         printf("%6d x %6d x %6d TFLOP/s (two passes): production plain %6.0f %6.0f  persistent %6.0f %6.0f | 4 waves 256x256 %6.0f %6.0f (mismatches %zu)  256x384 %6.0f %6.0f (mismatches %zu)\n",
                M, N, K, r[0][0], r[1][0], r[0][1], r[1][1], r[0][2], r[1][2], bad[0], r[0][3], r[1][3], bad[1]);
+        fflush(stdout);
+        hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dR);
+    }
+    // ---- transpose-read (weight-gradient) shapes: C[M][N] = A[K][M]^T B[K][N]
+    const int tshapes[][3] = {{16384, 2048, 30976}, {2048, 16384, 30976}, {8192, 8192, 8192}};
+    CK(hipFuncSetAttribute((const void*)gemm_w4_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    for (auto& sh : tshapes) {
+        const int M = sh[0], N = sh[1], K = sh[2];
+        std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
+        uint32_t s = 777;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        auto gauss = [&]() { return (rnd() + rnd() + rnd() + rnd()) * 1.732f; };
+        for (auto& v : hA) v = f2bf(gauss() * 0.05f);
+        for (auto& v : hB) v = f2bf(gauss());
+        bf16_t *dA, *dB, *dC, *dR;
+        CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2));
+        CK(hipMalloc(&dC, (size_t)M * N * 2)); CK(hipMalloc(&dR, (size_t)M * N * 2));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        auto timeit = [&](auto fn) {
+            for (int i = 0; i < 5; ++i) fn();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 10; ++i) fn();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            return 2.0 * M * N * K / (ms / 10 * 1e-3) / 1e12;
+        };
+        kai0_gemm_desc d; memset(&d, 0, sizeof d);
+        d.A = dA; d.B = dB; d.C = dR; d.M = M; d.N = N; d.K = K; d.a_kc = 0; d.b_kc = 0; d.lda = M; d.ldb = N; d.ldc = N;
+        d.batch = 1; d.batch_inner = 1; d.scale = 1.0f; d.split_k = 1;
+        auto prod = [&] { return timeit([&] { if (kai0_gemm_bf16(&d, nullptr)) { printf("gemm: %s\n", kai0_last_error()); exit(1); } }); };
+        auto w4 = [&] { return timeit([&] { hipLaunchKernelGGL(gemm_w4_tn, dim3((M / 256) * (N / 256)), dim3(256), 131072, 0, dA, dB, dC, M, N, K, M / 256, N / 256); }); };
+        prod();
+        double r[2][2];
+        size_t bad = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            r[pass][0] = prod();
+            r[pass][1] = w4();
+            if (pass == 0) {
+                std::vector<uint16_t> hC((size_t)M * N), hR((size_t)M * N);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hR.data(), dR, hR.size() * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < hC.size(); ++i) bad += hC[i] != hR[i];
+            }
+        }
+        CK(hipGetLastError());
+        printf("TN %6d x %6d x %6d TFLOP/s (two passes): production ring %6.0f %6.0f | 4 waves 256x256 %6.0f %6.0f (mismatches %zu)\n", M, N, K, r[0][0], r[1][0], r[0][1], r[1][1], bad);
         fflush(stdout);
         hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dR);
     }
