@@ -532,6 +532,14 @@ int kai0_sum_chunks(const void* src, int is_f32, int chunks, int64_t chunk_strid
 int kai0_adamw(float* master, float* m, float* v, const void* grad, int grad_f32, void* model_param,
                int param_f32, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                float bias_c1, float bias_c2, const float* clip_coef, kai0_stream_t stream);
+/* kai0_adamw for a [n_rows][row_len] parameter with mostly-zero gradient rows (the embedding table, modeling_gemma.py embed_tokens: a
+ * step touches <= B x 200 of 257152 rows).  A row with zero moments and a zero gradient is a fixed point of the update when
+ * 1 - lr*wd == 1.0f (required), so it is skipped after its gradient has been read; row_active (uint8 [n_rows], persistent: set when
+ * a row first sees a nonzero gradient, i.e. its moments may be nonzero; all 1 is always valid) tells which rows must be updated
+ * regardless.  Bit-identical to kai0_adamw on the same buffers. */
+int kai0_adamw_rows(float* master, float* m, float* v, const void* grad, int grad_f32, void* model_param, int param_f32,
+                    int64_t n_rows, int row_len, unsigned char* row_active, float lr, float beta1, float beta2, float eps, float wd,
+                    float bias_c1, float bias_c2, const float* clip_coef, kai0_stream_t stream);
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) ; norm_out[0] = sqrt(sumsq[0])
  * (torch.nn.utils.clip_grad_norm_) */
 int kai0_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, kai0_stream_t stream);

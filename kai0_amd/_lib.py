@@ -184,6 +184,7 @@ _PROTOS: dict[str, list] = {
     "kai0_sum_chunks": [c_p, c_i, c_i, c_i64, c_i64, c_p, c_p],
     "kai0_clip_coef": [c_p, c_f, c_p, c_p, c_p],
     "kai0_adamw": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
+    "kai0_adamw_rows": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_i, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
 }  # fmt: skip
 
 EXPORTED_SYMBOLS = ("kai0_last_error", "kai0_skinny_workspace_bytes", "kai0_attn_decode_workspace_bytes", "kai0_gemm_f32_workspace_bytes",

@@ -117,6 +117,49 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     }
 }
 
+// The same update for a [rows][row_len] parameter whose gradient is zero in most rows (the 257152 x 2048 embedding table: a step
+// touches at most B x 200 of its rows).  A row whose moments are exactly zero and whose gradient is zero is a FIXED POINT of the
+// update above when 1 - lr*wd rounds to 1 (the host checks lr*wd < 2^-25): m and v stay 0, the step is 0/eps = 0, p * 1 = p.  Such
+// rows are skipped after reading only their gradient; `active[row]` (persistent, uint8) records that a row has ever seen a nonzero
+// gradient, i.e. that its moments may be nonzero.  Every element that IS updated goes through exactly adamw_kernel's arithmetic,
+// so the result is bit-identical to the dense pass — at 2 B instead of 28 B per element of an idle row.
+template <bool GF32, bool PF32>
+__global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                         const void* __restrict__ grad, void* __restrict__ param, int64_t n_rows,
+                                                         int row_len, unsigned char* __restrict__ active, float lr, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2, const float* __restrict__ coef) {
+    const float cc = coef ? coef[0] : 1.0f;
+    const float inv_bc1 = 1.0f / bc1;
+    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        const int64_t base = row * row_len;
+        int nz = 0;
+        for (int c = threadIdx.x; c < row_len; c += 256) {
+            const float g = GF32 ? reinterpret_cast<const float*>(grad)[base + c] : bf2f(reinterpret_cast<const bf16_t*>(grad)[base + c]);
+            nz |= (g != 0.0f);
+        }
+        const int any = __syncthreads_or(nz);
+        if (!any && !active[row]) continue;  // (block-uniform)
+        if (any && threadIdx.x == 0) active[row] = 1;
+        for (int c = threadIdx.x; c < row_len; c += 256) {
+            const int64_t i = base + c;
+            float g = GF32 ? reinterpret_cast<const float*>(grad)[i] : bf2f(reinterpret_cast<const bf16_t*>(grad)[i]);
+            g *= cc;
+            float p = master[i];
+            float mi = m[i] * b1 + (1.0f - b1) * g;
+            float vi = v[i] * b2 + (1.0f - b2) * g * g;
+            p = p * (1.0f - lr * wd);
+            const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+            p = p - (lr * inv_bc1) * (mi / denom);
+            master[i] = p;
+            m[i] = mi;
+            v[i] = vi;
+            if (PF32) reinterpret_cast<float*>(param)[i] = p;
+            else reinterpret_cast<bf16_t*>(param)[i] = f2bf(p);
+        }
+    }
+}
+
 inline int opt_grid(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -172,4 +215,24 @@ KAI0_API int kai0_adamw(float* master, float* m, float* v, const void* grad, int
     else LAUNCH(false, false);
 #undef LAUNCH
     return kai0_check_launch("kai0_adamw");
+}
+
+KAI0_API int kai0_adamw_rows(float* master, float* m, float* v, const void* grad, int grad_f32, void* model_param, int param_f32,
+                             int64_t n_rows, int row_len, unsigned char* row_active, float lr, float beta1, float beta2, float eps,
+                             float wd, float bias_c1, float bias_c2, const float* clip_coef, kai0_stream_t stream) {
+    if (n_rows <= 0) return 0;
+    KAI0_REQUIRE(master && m && v && grad && model_param && row_active && row_len > 0, "kai0_adamw_rows: null buffer");
+    KAI0_REQUIRE(1.0f - lr * wd == 1.0f, "kai0_adamw_rows: lr * wd = %g does not round away (1 - lr*wd must be 1.0f): idle rows are not fixed points, use kai0_adamw",
+                 (double)lr * (double)wd);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)(n_rows < 16384 ? n_rows : 16384)), block(256);
+#define LAUNCH(G, P)                                                                                                          \
+    hipLaunchKernelGGL((adamw_rows_kernel<G, P>), grid, block, 0, s, master, m, v, grad, model_param, n_rows, row_len, row_active, lr, \
+                       beta1, beta2, eps, wd, bias_c1, bias_c2, clip_coef)
+    if (grad_f32 && param_f32) LAUNCH(true, true);
+    else if (grad_f32) LAUNCH(true, false);
+    else if (param_f32) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return kai0_check_launch("kai0_adamw_rows");
 }

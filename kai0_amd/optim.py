@@ -42,6 +42,24 @@ def adamw_step_(master, m, v, grad, param, *, lr, beta1, beta2, eps, wd, step: i
               None if clip_coef is None else clip_coef.data_ptr(), _stream())  # fmt: skip
 
 
+def sparse_rows_ok(lr: float, wd: float) -> bool:
+    """True if an idle row (zero moments, zero gradient) is a fixed point of the update: 1 - lr*wd rounds to 1 in f32."""
+    return bool(np.float32(1.0) - np.float32(lr) * np.float32(wd) == np.float32(1.0))
+
+
+def adamw_rows_step_(master, m, v, grad, param, row_len: int, row_active, *, lr, beta1, beta2, eps, wd, step: int, clip_coef=None):
+    """kai0_adamw_rows: the same update on a flat [rows * row_len] range whose gradient is zero in most rows (embedding table);
+    bit-identical to adamw_step_, idle rows cost their gradient read only.  row_active: uint8 [rows], persistent."""
+    WEIGHT_UPDATES[0] += 1
+    n = master.numel()
+    assert n % row_len == 0 and row_active.numel() == n // row_len and row_active.dtype == torch.uint8
+    bc1 = 1.0 - beta1**step
+    bc2 = 1.0 - beta2**step
+    _lib.call("kai0_adamw_rows", master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), int(grad.dtype == F32),
+              param.data_ptr(), int(param.dtype == F32), n // row_len, row_len, row_active.data_ptr(), lr, beta1, beta2, eps, wd,
+              bc1, bc2, None if clip_coef is None else clip_coef.data_ptr(), _stream())  # fmt: skip
+
+
 _SUMSQ_SCRATCH: dict = {}
 
 

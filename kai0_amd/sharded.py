@@ -75,6 +75,13 @@ class HipShardOps:
         adamw_step_(master, m, v, grad, param, lr=lr, beta1=beta1, beta2=beta2, eps=eps, wd=wd, step=step, clip_coef=clip_coef)
 
 
+    def adamw_rows(self, master, m, v, grad, param, row_len, row_active, *, lr, beta1, beta2, eps, wd, step, clip_coef):
+        from .optim import adamw_rows_step_
+
+        adamw_rows_step_(master, m, v, grad, param, row_len, row_active, lr=lr, beta1=beta1, beta2=beta2, eps=eps, wd=wd, step=step,
+                         clip_coef=clip_coef)  # fmt: skip
+
+
 class _Bucket:
     """Flat buffers of the same-dtype parameters of a run of consecutive units."""
 
@@ -293,6 +300,8 @@ class ShardedDataParallel:
         self._coef = torch.ones(1, dtype=F32, device=self.device)
         self._norm = torch.zeros(1, dtype=F32, device=self.device)
         self._in_backward = False
+        # KAI0_SPARSE_EMBED=0: the embedding table's rows all go through the dense update (A/B; the result is bit-identical)
+        self._sparse_rows = os.environ.get("KAI0_SPARSE_EMBED", "1") != "0"
         self._rs_inflight: list[_Bucket] = []  # fsdp: buckets whose reduce-scatter runs out of a staging buffer
         self.comm_profile = False
         self._comm_events: list[tuple[str, object, object]] = []
@@ -592,8 +601,7 @@ class ShardedDataParallel:
             self.ops.clip_coef(self._sumsq, self.max_grad_norm, self._coef, self._norm)
             coef = self._coef
         for b in self.buckets:  # forward-use order: the first layers' parameters are complete first
-            self.ops.adamw(b.master, b.exp_avg, b.exp_avg_sq, b.grad_shard, b.param_shard, lr=lr, beta1=self.betas[0],
-                           beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self.step_count, clip_coef=coef)  # fmt: skip
+            self._update_bucket(b, lr, coef)
             if not b.fsdp:
                 b.ag_work = self._all_gather(b)  # not waited for here: pre_forward / wait_params do
         # Every gradient producer overwrites its parameter's whole slice, so the 7 GB of flat gradients are NOT cleared per
@@ -626,6 +634,53 @@ class ShardedDataParallel:
             self.release_params()
             self._issue_gather(0)  # the next forward starts with group 0
         return self._norm
+
+    # ---- optimizer update of one bucket's shard ---------------------------------------------------------------
+    _SPARSE_MIN_ROWS = 1024
+
+    def _sparse_segments(self, b: _Bucket):
+        """Row-sparse ranges of this rank's shard of `b`: [(first element in the shard, rows, row length, activity flags)] for every
+        large 2-D parameter whose gradient producer scatters into a zeroed slice (`_kai0_grad_accumulates`: the embedding table —
+        a step touches <= B x 200 of its 257152 rows).  Whole rows only; what a shard boundary cuts off is updated densely."""
+        key = tuple(id(p) for p in b.params if getattr(p, "_kai0_grad_accumulates", False))
+        if getattr(b, "_sparse_key", None) == key:
+            return b._sparse_segs
+        segs = []
+        for p, o in zip(b.params, b.offsets):
+            if not getattr(p, "_kai0_grad_accumulates", False) or p.dim() != 2 or p.shape[0] < self._SPARSE_MIN_ROWS:
+                continue
+            rl = int(p.shape[1])
+            lo, hi = max(o, b.lo), min(o + p.numel(), b.lo + b.shard)
+            r0, r1 = -(-(lo - o) // rl), (hi - o) // rl  # whole rows inside [lo, hi)
+            if r1 > r0:
+                first = o + r0 * rl - b.lo
+                # a row is active once its moments may be nonzero: rebuilt from them, so a loaded checkpoint needs nothing extra
+                mm = b.exp_avg[first : first + (r1 - r0) * rl].view(r1 - r0, rl)
+                vv = b.exp_avg_sq[first : first + (r1 - r0) * rl].view(r1 - r0, rl)
+                active = ((mm != 0).any(1) | (vv != 0).any(1)).to(torch.uint8)
+                segs.append((first, r1 - r0, rl, active))
+        b._sparse_key, b._sparse_segs = key, segs
+        return segs
+
+    def _update_bucket(self, b: _Bucket, lr: float, coef):
+        kw = dict(lr=lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self.step_count, clip_coef=coef)
+        segs = []
+        if self._sparse_rows and hasattr(self.ops, "adamw_rows") and self.device.type == "cuda":
+            from .optim import sparse_rows_ok
+
+            if sparse_rows_ok(lr, self.wd):  # an idle row must be a fixed point of the update (1 - lr*wd rounds to 1)
+                segs = self._sparse_segments(b)
+        cur = 0
+        for first, rows, rl, active in segs:
+            if first > cur:
+                self.ops.adamw(b.master[cur:first], b.exp_avg[cur:first], b.exp_avg_sq[cur:first], b.grad_shard[cur:first],
+                               b.param_shard[cur:first], **kw)  # fmt: skip
+            end = first + rows * rl
+            self.ops.adamw_rows(b.master[first:end], b.exp_avg[first:end], b.exp_avg_sq[first:end], b.grad_shard[first:end],
+                                b.param_shard[first:end], rl, active, **kw)  # fmt: skip
+            cur = end
+        if cur < b.shard:
+            self.ops.adamw(b.master[cur:], b.exp_avg[cur:], b.exp_avg_sq[cur:], b.grad_shard[cur:], b.param_shard[cur:], **kw)
 
     # ------------------------------------------------------------------------------------------ checkpointing
     @torch.no_grad()
@@ -707,6 +762,8 @@ class ShardedDataParallel:
             logging.getLogger("kai0_amd").warning(
                 "optimizer state has no entry for %d parameter(s) (never updated when it was written; zero moments assumed): %s%s",
                 len(absent), ", ".join(absent[:4]), " ..." if len(absent) > 4 else "")  # fmt: skip
+        for b in self.buckets:
+            b._sparse_key = None  # the row-activity flags are rebuilt from the loaded moments at the next step
         self.wait_params()
         self._check_views()
         for b, lo, hi in from_params:  # the alignment padding between parameters keeps whatever the master held (zeros)

@@ -735,6 +735,44 @@ def test_adamw_and_clip(ops):
         assert torch.equal(p.detach(), m.to(p.dtype))
 
 
+@pytest.mark.parametrize("gdtype", [BF16, F32])
+def test_adamw_rows_is_bit_identical_to_the_dense_update(ops, gdtype):
+    """kai0_adamw_rows (embedding table: rows with zero moments and a zero gradient are skipped) against kai0_adamw on the same
+    buffers over six steps: a different sparse set of rows receives gradients every step (so rows turn active over time and keep
+    being updated with a zero gradient afterwards), clip coefficient from device memory, negative zeros among the gradients."""
+    from kai0_amd import optim
+
+    rows, rl = 3000, 264
+    n = rows * rl
+    g0 = torch.Generator(device=dev()).manual_seed(3)
+    p0 = (torch.randn(n, device=dev(), generator=g0) * 0.02).to(BF16)
+    state = {k: [p0.float().clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev()), p0.clone()] for k in ("dense", "rows")}
+    active = torch.zeros(rows, dtype=torch.uint8, device=dev())
+    coef = torch.tensor([0.37], device=dev())
+    kw = dict(beta1=0.9, beta2=0.95, eps=1e-8, wd=1e-10)
+    assert optim.sparse_rows_ok(2.5e-5, 1e-10) and not optim.sparse_rows_ok(2.5e-5, 1e-2)
+    touched = torch.zeros(rows, dtype=torch.bool, device=dev())
+    for step in range(1, 7):
+        grad = torch.zeros(rows, rl, device=dev())
+        idx = torch.randperm(rows, device=dev(), generator=g0)[: 40 + 10 * step]
+        grad[idx] = torch.randn(idx.numel(), rl, device=dev(), generator=g0)
+        grad[idx[:3], ::2] = -0.0
+        touched[idx] = True
+        grad = grad.reshape(-1).to(gdtype)
+        lr = 2.5e-5 * step / 6
+        m, e, v, p = state["dense"]
+        optim.adamw_step_(m, e, v, grad, p, lr=lr, step=step, clip_coef=coef, **kw)
+        m, e, v, p = state["rows"]
+        optim.adamw_rows_step_(m, e, v, grad, p, rl, active, lr=lr, step=step, clip_coef=coef, **kw)
+    for a, b in zip(state["dense"], state["rows"]):
+        assert torch.equal(a, b)
+    assert torch.equal(active.bool(), touched)
+    assert bool((state["rows"][1].view(rows, rl)[~touched] == 0).all())  # idle rows: moments still exactly zero
+    with pytest.raises(Exception, match="does not round away"):
+        m, e, v, p = state["rows"]
+        optim.adamw_rows_step_(m, e, v, grad, p, rl, active, lr=1e-3, step=7, clip_coef=coef, beta1=0.9, beta2=0.95, eps=1e-8, wd=1e-2)
+
+
 @pytest.mark.parametrize("kind,M,N,K,split", [(2, 768, 1152, 4304, 4), (2, 768, 1152, 1152, 3), (1, 968, 2048, 16384, 6), (1, 50, 64, 512, 2),
                                              (2, 37, 1152, 4304, 12)])
 def test_splitk_gemm_with_the_consumer_norm_in_its_reduction(ops, kind, M, N, K, split):

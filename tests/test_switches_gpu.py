@@ -27,6 +27,7 @@ SWITCHES = [
     ({"KAI0_SKIP_DEAD_PREFIX": "0"}, True),                     # the last layer's dead prefix o_proj / MLP computed
     ({"KAI0_ZERO_GRADS": "full"}, True),                        # flat gradient buffers cleared every step
     ({"KAI0_DEFER_REDUCE": "0"}, True),                         # norm-weight / bias gradient sums launched one by one, not queued
+    ({"KAI0_SPARSE_EMBED": "0"}, True),                         # embedding table through the dense AdamW pass (no idle-row skip)
     ({"KAI0_EXPERT_STREAM": "0"}, True),                        # action expert's chain on the main stream
     ({"KAI0_SK2_PACKED": "0"}, True),                           # denoise kernels: row-major instead of fragment-major weights
     ({"KAI0_INFER_FUSE_NORM": "0", "KAI0_PREFIX_SPLITS": "1,1,6"}, False),  # norms as launches of their own, unsplit o_proj
