@@ -134,9 +134,17 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ mas
     for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
         const int64_t base = row * row_len;
         int nz = 0;
-        for (int c = threadIdx.x; c < row_len; c += 256) {
-            const float g = GF32 ? reinterpret_cast<const float*>(grad)[base + c] : bf2f(reinterpret_cast<const bf16_t*>(grad)[base + c]);
-            nz |= (g != 0.0f);
+        if (!GF32 && (row_len & 7) == 0 && ((uintptr_t)grad & 15) == 0) {
+            // the scan is what an idle row costs: 16 B per lane, "nonzero" = any bit besides the signs (-0.0 is a zero gradient)
+            for (int c = threadIdx.x * 8; c < row_len; c += 256 * 8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(grad) + base + c);
+                nz |= ((u.x | u.y | u.z | u.w) & 0x7fff7fffu) != 0u;
+            }
+        } else {
+            for (int c = threadIdx.x; c < row_len; c += 256) {
+                const float g = GF32 ? reinterpret_cast<const float*>(grad)[base + c] : bf2f(reinterpret_cast<const bf16_t*>(grad)[base + c]);
+                nz |= (g != 0.0f);
+            }
         }
         const int any = __syncthreads_or(nz);
         if (!any && !active[row]) continue;  // (block-uniform)
