@@ -379,17 +379,30 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const bf16_t* __restric
     if (found) earlier = 1;  // benign race: all writers store 1
     __syncthreads();
     if (earlier) return;
+    // the occurrences of this token among tokens i..n-1 as a bitmap (built by all threads at once), then walked in ascending order:
+    // the f32 sum keeps its fixed order, and the walk costs n/32 word tests instead of n token compares per thread
+    extern __shared__ unsigned int occ[];
+    const int nw = (n - i + 31) >> 5;
+    for (int w = threadIdx.x; w < nw; w += 256) occ[w] = 0u;
+    __syncthreads();
+    for (int j = i + threadIdx.x; j < n; j += 256)
+        if (tok[j] == my) atomicOr(&occ[(j - i) >> 5], 1u << ((j - i) & 31));
+    __syncthreads();
     for (int c0 = threadIdx.x * 8; c0 < D; c0 += 256 * 8) {
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int j = i; j < n; ++j) {
-            if (tok[j] != my) continue;  // block-uniform
-            const int b = j / T, t = j - b * T;
-            float v[8];
-            ld8(dout + (int64_t)b * bs + (row0 + t) * ld + c0, v);
+        for (int w = 0; w < nw; ++w) {
+            unsigned int bits = occ[w];  // (block-uniform)
+            while (bits) {
+                const int j = i + (w << 5) + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int b = j / T, t = j - b * T;
+                float v[8];
+                ld8(dout + (int64_t)b * bs + (row0 + t) * ld + c0, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += rbf(v[e] * scale);
+                for (int e = 0; e < 8; ++e) acc[e] += rbf(v[e] * scale);
+            }
         }
         st8(dtable + my * (int64_t)D + c0, acc);
     }
@@ -759,7 +772,8 @@ KAI0_API int kai0_embed_grad(const void* dout, const int64_t* tokens, void* dtab
                              int64_t dout_bs, int64_t dout_row0, int64_t dout_ld, kai0_stream_t stream) {
     KAI0_REQUIRE(D % 8 == 0 && dout_ld % 8 == 0, "kai0_embed_grad: D and dout_ld must be multiples of 8");
     if (B * T <= 0) return 0;
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(B * T), dim3(256), 0, S_(stream), (const bf16_t*)dout, tokens,
+    KAI0_REQUIRE((int64_t)B * T <= 32 * 16000, "kai0_embed_grad: B*T = %lld tokens exceed the occurrence bitmap (512000)", (long long)B * T);
+    hipLaunchKernelGGL(embed_grad_kernel, dim3(B * T), dim3(256), (size_t)((B * T + 31) / 32) * 4, S_(stream), (const bf16_t*)dout, tokens,
                        (bf16_t*)dtable, B * T, T, D, scale, dout_bs, dout_row0, dout_ld);
     return kai0_check_launch("kai0_embed_grad");
 }
