@@ -149,6 +149,7 @@ _PROTOS: dict[str, list] = {
     "kai0_colsum_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_p],
     "kai0_reduce_partials_batch": [c_p, c_i, c_p],
     "kai0_pack_rows": [c_p, c_i, c_p, c_i64, c_p, c_i, c_p],
+    "kai0_sampled_checksum": [c_p, c_i, c_i, c_p, c_p],
     "kai0_colsum_partials_bf16": [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p],
     "kai0_rope_inplace": [c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rope_inplace2": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_p],

@@ -520,6 +520,33 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     }
 }
 
+// Sampled content checksum of a list of buffers (device array of {pointer, bytes}): every `stride`-th 16-byte chunk of each buffer,
+// mixed with its position, summed into one 64-bit integer (integer addition: order-free, hence deterministic).  The inference engine
+// stamps the tensors its derived weight copies were cut from with it at the end of every action chunk, so that an in-place edit
+// of a weight that bypasses autograd's version counters (`p.data.mul_()`, a foreign kernel) is noticed (infer.py `_content_ok`).
+__global__ __launch_bounds__(256) void sampled_checksum_kernel(const kai0_ck_item* __restrict__ items, int n, int stride,
+                                                               unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (int it = blockIdx.y; it < n; it += gridDim.y) {
+        const kai0_ck_item item = items[it];
+        const int64_t chunks = item.nbytes >> 4;
+        const int64_t ns = (chunks + stride - 1) / stride;
+        const uint4* base = reinterpret_cast<const uint4*>(item.ptr);
+        for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < ns; k += (int64_t)gridDim.x * 256) {
+            int64_t c = k * stride + ((it * 7 + k) % stride);  // (a different phase per sample: no fixed column is blind)
+            if (c >= chunks) c = chunks - 1;
+            const uint4 u = base[c];
+            const unsigned long long lo = ((unsigned long long)u.y << 32) | u.x, hi = ((unsigned long long)u.w << 32) | u.z;
+            acc += (lo ^ (hi * 0x9E3779B97F4A7C15ull)) * (2ull * (unsigned long long)(c + it) + 1ull);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
 // bf16 matrix transpose through LDS: src [R][C] -> dst [C][R]; 64x64 tiles, 16-B global accesses both ways.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
                                                         int64_t src_ld, int64_t dst_ld, int64_t src_bs, int64_t dst_bs) {
@@ -834,6 +861,11 @@ KAI0_API int kai0_pack_rows(const kai0_pack_part* parts, int n, const int32_t* p
     a.pos = pos; a.inv_freq = inv_freq; a.pos_bs = pos_bs; a.n = n; a.HD = HD;
     hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, S_(stream), a);
     return kai0_check_launch("kai0_pack_rows");
+}
+KAI0_API int kai0_sampled_checksum(const kai0_ck_item* items_dev, int n, int stride, unsigned long long* out_dev, kai0_stream_t stream) {
+    KAI0_REQUIRE(items_dev != nullptr && out_dev != nullptr && n > 0 && stride > 0, "kai0_sampled_checksum: empty");
+    hipLaunchKernelGGL(sampled_checksum_kernel, dim3(8, n < 512 ? n : 512), dim3(256), 0, S_(stream), items_dev, n, stride, out_dev);
+    return kai0_check_launch("kai0_sampled_checksum");
 }
 KAI0_API int kai0_transpose_bf16(const void* src, void* dst, int R, int C, kai0_stream_t stream) {
     KAI0_REQUIRE(R % 8 == 0 && C % 8 == 0, "kai0_transpose_bf16: R=%d and C=%d must be multiples of 8", R, C);

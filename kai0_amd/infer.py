@@ -101,9 +101,49 @@ class InferenceEngine:
         self._graph_steps = None
         self._static_in = None
         self._static_out = None
+        self._content_init()
 
     def compatible(self, batch, n_lang, n_cam):
-        return (batch, n_lang, n_cam) == (self.B, self.T, self.ncam) and self._weights_tag == self._fingerprint()
+        return ((batch, n_lang, n_cam) == (self.B, self.T, self.ncam) and self._weights_tag == self._fingerprint()
+                and self._content_ok())  # fmt: skip
+
+    # ---- content stamp of the source weights (the engine-invalidation contract, checked) ------------------------------------
+    _CK_STRIDE = 32  # every 32nd 16-byte chunk: ~30 MB of the ~1 GB the derived copies were cut from, a few microseconds
+
+    def _content_init(self):
+        """The tensors of `_fingerprint` are also summed by content (kai0_sampled_checksum) at the end of every action chunk, inside
+        the captured graph, and the sum lands in pinned host memory without a synchronisation.  `compatible()` compares the last
+        landed sum with the one taken when the derived copies were built: an in-place edit that neither autograd's version counters
+        nor the optimizer's update counter see (`p.data.mul_()`, a foreign kernel) drops the engine at the NEXT call at the latest
+        — `stale()` tells a caller that has synchronised (Policy.infer) whether the chunk it just got was computed from edited
+        weights, so the serve path never returns one.  Sampled: bulk edits (model arithmetic, a loaded checkpoint) are certain to
+        be seen, a single edited element is not.  KAI0_INFER_CHECKSUM=0 disables the stamp."""
+        self._ck_on = os.environ.get("KAI0_INFER_CHECKSUM", "1") != "0" and self.dev.type == "cuda"
+        if not self._ck_on:
+            return
+        srcs = [p for p in self._fp_srcs if p.numel() * p.element_size() >= 16 and p.data_ptr() % 16 == 0 and p.is_contiguous()]
+        self._ck_items = torch.tensor([[p.data_ptr(), p.numel() * p.element_size()] for p in srcs], dtype=torch.int64).to(self.dev)
+        self._ck_n = len(srcs)
+        self._ck_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self._ck_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._content_stamp()
+        torch.cuda.current_stream().synchronize()
+        self._ck_ref = int(self._ck_host[0])
+
+    def _content_stamp(self):
+        if not self._ck_on:
+            return
+        self._ck_dev.zero_()
+        _lib.call("kai0_sampled_checksum", self._ck_items.data_ptr(), self._ck_n, self._CK_STRIDE, self._ck_dev.data_ptr(), ops._stream())
+        self._ck_host.copy_(self._ck_dev, non_blocking=True)
+
+    def _content_ok(self) -> bool:
+        """False once a completed chunk has stamped source weights that differ from the ones the derived copies were built from."""
+        return not self._ck_on or int(self._ck_host[0]) == self._ck_ref
+
+    def stale(self) -> bool:
+        """After the caller has synchronised with the last chunk: was it computed while the source weights had been edited?"""
+        return not self._content_ok()
 
     def _fingerprint(self):
         """Identity of the weights this engine (its stacked copies and its captured graph) was built from: storage and
@@ -599,10 +639,12 @@ class InferenceEngine:
                 ops.denoise_glue(x2, xs=last, mod=mf[rows], mod_ld=self._mod_ld, rows_per_batch=Hs, eps=eps, w_out=wout, b_out=bout,
                                  dt=dt, w_in=win if xs is not None else None, b_in=bin_ if xs is not None else None, xs_next=xs,
                                  rowsq_next=sq)
+            self._content_stamp()
             return x_t
         for step in range(len(times)):
             v_t = self._denoise_step(x_t, step, mods, mf)
             ops.euler_step_(x_t, v_t, dt)
+        self._content_stamp()
         return x_t
 
     # -------------------------------------------------------------------------------------------------- API

@@ -515,6 +515,12 @@ class PI0Pytorch(nn.Module):
     def invalidate_inference_engine(self):
         self._engine = None
 
+    def inference_is_stale(self) -> bool:
+        """True if the last action chunk (the caller has synchronised with it) was computed while a source weight of the engine's
+        derived copies had been edited in place behind autograd's back (infer.InferenceEngine._content_init)."""
+        eng = self._engine
+        return eng is not None and eng.stale()
+
     def train(self, mode: bool = True):
         if mode:
             self._engine = None
@@ -692,6 +698,8 @@ class PI0Pytorch(nn.Module):
             lang_tokens, lang_masks = self._trim_prompt(lang_tokens, lang_masks, granule=self.trim_prompt_granule_infer)
         key = (bsize, lang_tokens.shape[1], len(images))
         eng = self._engine
+        if eng is not None and eng.stale():  # weights edited in place behind autograd's back: every cached engine holds old copies
+            self._engine = eng = None
         if eng is None or not eng.compatible(*key):
             lru = self.__dict__.setdefault("_engine_lru", {})
             eng = lru.pop(key, None)

@@ -67,6 +67,10 @@ class Policy(BasePolicy):
         outputs = {"state": inputs["state"], "actions": self._sample_actions(dev, observation, **kwargs)}
         if torch.device(dev).type == "cuda":
             torch.cuda.synchronize()  # sample_actions returns as soon as the graph is launched
+            stale = getattr(self._model, "inference_is_stale", None)
+            if stale is not None and stale():  # the chunk was computed from weights edited in place: rebuilt and computed again
+                outputs["actions"] = self._sample_actions(dev, observation, **kwargs)
+                torch.cuda.synchronize()
         model_time = time.monotonic() - t0
         outputs = _map_leaves(lambda x: np.asarray(x[0, ...].detach().cpu()), outputs)
         outputs = self._output_transform(outputs)

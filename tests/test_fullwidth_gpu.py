@@ -303,3 +303,33 @@ def test_fullwidth_chunk_switches_agree(fw, monkeypatch):
     finally:
         m.invalidate_inference_engine()
         m.train()
+
+
+def test_fullwidth_engine_notices_a_weight_edit_behind_autograd(fw):
+    """At the real widths the denoise loop reads only packed / folded COPIES of the expert's projections: after `w.data.mul_()` (no new
+    storage, no version bump) the next chunk is still the old one — and is flagged by the content stamp; the call after it runs on a
+    rebuilt engine (VERDICT r3 #13)."""
+    from test_fullsize_gpu import _take
+
+    m, d = fw["model"], dev()
+    w = m.paligemma_with_expert.gemma_expert.model.layers[0].mlp.down_proj.weight
+    m.eval()
+    try:
+        gobs, noise = _take(fw["gobs"], 1), fw["noise"][1:2].to(d)
+        m.invalidate_inference_engine()
+        before = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        eng = m._engine
+        torch.cuda.synchronize()
+        assert eng.skinny and not m.inference_is_stale()
+        saved = w.data.clone()
+        w.data.mul_(1.25)
+        stale_chunk = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        torch.cuda.synchronize()
+        assert m._engine is eng and torch.equal(stale_chunk, before) and m.inference_is_stale()
+        after = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        torch.cuda.synchronize()
+        assert m._engine is not eng and not torch.equal(after, before) and not m.inference_is_stale()
+        w.data.copy_(saved)
+    finally:
+        m.invalidate_inference_engine()
+        m.train()

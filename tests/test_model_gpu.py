@@ -574,6 +574,46 @@ def test_trimmed_prompt_gives_the_same_action_chunk_and_engines_are_kept_per_sha
         m.train()
 
 
+def test_in_place_weight_edit_behind_autograd_is_noticed_by_the_engine(pair):
+    """the engine's derived weight copies (stacked q|k|v, packed / folded expert weights) are keyed on storage +
+    autograd version + the optimizer's update counter; `p.data.mul_()` changes none of them.  The content stamp taken inside every
+    action chunk notices it: the chunk computed right after the edit is flagged (`inference_is_stale`), the engine is dropped at the
+    next call, and from then on the chunks equal those of an engine built from the edited weights."""
+    m, dev = pair["model"], pair["dev"]
+    obs, noise = pair["gobs"], pair["noise"].to(dev)
+    w = m.paligemma_with_expert.gemma_expert.model.layers[0].self_attn.q_proj.weight
+    m.eval()
+    try:
+        m.invalidate_inference_engine()
+        before = m.sample_actions(dev, obs, noise=noise, num_steps=10)
+        eng = m._engine
+        torch.cuda.synchronize()
+        assert not m.inference_is_stale()
+        assert torch.equal(m.sample_actions(dev, obs, noise=noise, num_steps=10), before) and m._engine is eng
+        saved = w.data.clone()
+        v0 = w._version
+        w.data.mul_(1.5)  # neither a new storage nor a version bump nor an optimizer update
+        assert w._version == v0 and eng.compatible(eng.B, eng.T, eng.ncam)  # ... so the old key still matches
+        m.sample_actions(dev, obs, noise=noise, num_steps=10)  # computed from whatever copies the engine holds of w (full width: all)
+        torch.cuda.synchronize()
+        assert m._engine is eng and m.inference_is_stale()
+        second = m.sample_actions(dev, obs, noise=noise, num_steps=10)  # the stamp has landed: engine rebuilt
+        torch.cuda.synchronize()
+        assert m._engine is not eng and not m.inference_is_stale()
+        m.invalidate_inference_engine()
+        fresh = m.sample_actions(dev, obs, noise=noise, num_steps=10)
+        assert torch.equal(second, fresh) and not torch.equal(second, before)
+        w.data.copy_(saved)
+        torch.cuda.synchronize()
+        m.sample_actions(dev, obs, noise=noise, num_steps=10)
+        torch.cuda.synchronize()
+        assert m.inference_is_stale()
+        assert torch.equal(m.sample_actions(dev, obs, noise=noise, num_steps=10), before)
+    finally:
+        m.invalidate_inference_engine()
+        m.train()
+
+
 @pytest.mark.timeout(600)
 def test_train_loop_debug_pi05_resume_is_exact(tmp_path):
     """`train_loop(get_config("debug_pi05"))` over the HIP model (scripts/train_pytorch.py:309-633): 6 steps in one
