@@ -12,7 +12,7 @@
 //     inside the stated floating-point tolerance, not bit-identical to eager_attention_forward.
 //   * the former "two-pass" form (OP = 0: pass 1 row max / row sum, pass 2 recomputes the logits, writes the FINAL normalised P
 //     and accumulates O with that bf16 P — bitwise the reference's rounding order) is kept for callers that ask for P and as the
-//     A/B alternative (KAI0_ATTN_ONLINE=0).
+//     A/B alternative (ops.py: KAI0_ATTN_STORE_P=1).
 //   * transposed orientation: S^T = K Q^T and O^T = V^T P^T.  The C-layout of S^T (lane = query column, registers =
 //     4 consecutive keys) IS the B-operand layout of the second MFMA, so P never leaves registers; softmax statistics
 //     are per lane (no cross-lane traffic in the key loop); V^T comes from a row-major V tile through
@@ -63,7 +63,7 @@ struct AttnArgs {
     int kc_lds_keys;  // > 0: the key codes of the launch's key range are staged in LDS once per block (round_up(Sk, 64) entries)
     float* lse;          // optional [batch][s_lse] f32: log-sum-exp of every query row's logits (+inf for rows that see no key)
     int64_t s_lse;
-    int nt_p;    // P stored with the non-temporal hint (KAI0_ATTN_NT_P, default 1)
+    int nt_p;    // P stored with the non-temporal hint
     int ablate;  // diagnostics only (KAI0_ATTN_ABLATE bit mask, timing runs): 1 no P store, 2 no pass 1, 4 no P V MFMAs,
                  // 8 no DMA inside the tile loops, 16 no logits MFMAs in pass 2 — results are wrong with any bit set
 };
