@@ -148,6 +148,119 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(const bf16_t* __restrict__ A, 
     }
 }
 
+// The same four-wave loop on 32 x 32 x 16 MFMAs (32 cycles each instead of 16: half as many issue slots per K-tile, twice the room
+// behind each one for the ~60-cycle LDS-DMA issue).  Wave tile 128 x 128 = 4 x 4 tiles of 32 x 32; a K-tile = two halves of two
+// 16-deep steps; fragment f = tile * 2 + step: lane -> row (lane % 32) of the tile, 16-B chunk 2 * step + lane / 32 of the half.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__global__ __launch_bounds__(256, 1) void gemm_w4_m32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M,
+                                                      int N, int K, int tiles_m, int tiles_n) {
+    constexpr int TM = 256, TN = 256, A_TILE = TM * 128, STAGE = 2 * A_TILE, NP = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = pid & 7, idx = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP = 4;
+    const int width = GROUP * tiles_n, group = pid / width, first_m = group * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP), in_g = pid - group * width;
+    const int m0 = (first_m + in_g % gsz) * TM, n0 = (in_g / gsz) * TN;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    const int nk = K / BK;
+    uint32_t voff[NP];
+    const uint32_t kc2 = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = wave * NP + j;
+        const int row = (q < 32 ? m0 + q * 8 : n0 + (q - 32) * 8) + (lane >> 3);
+        voff[j] = (uint32_t)row * (uint32_t)K * 2 + kc2;
+    }
+    auto issue = [&](int j, int tbytes, int slot) {
+        const int q = wave * NP + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < 32 ? a_rsrc : b_rsrc, (LDS_PTR(void))(smem + slot * STAGE + q * 1024), 16, (int)voff[j], tbytes, 0, 0);
+    };
+    // fragment (tile t, half h, step k2): row = w*128 + t*32 + l31, chunk = h*4 + k2*2 + hi, swizzled by row & 7
+    const int fa = (wm * 128 + l31) * 128, fb = A_TILE + (wn * 128 + l31) * 128;
+    const int r7 = l31 & 7;
+    auto frag = [&](int slot, int base, int t, int h, int k2) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(smem + slot * STAGE + base + t * 4096 + (((h * 4 + k2 * 2 + hi) ^ r7) << 4));
+    };
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue(j, min(1, nk - 1) * (BK * 2), 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        a0[f] = frag(0, fa, f >> 1, 0, f & 1);
+        b0[f] = frag(0, fb, f >> 1, 0, f & 1);
+    }
+    for (int t = 0; t < nk; ++t) {
+        const int slot = t & 1;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {  // f = tile * 2 + step
+            a1[f] = frag(slot, fa, f >> 1, 1, f & 1);
+            b1[f] = frag(slot, fb, f >> 1, 1, f & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[f >> 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[f], b0[j * 2 + (f & 1)], acc[f >> 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int tn = min(t + 2, nk - 1) * (BK * 2);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            issue(2 * f, tn, slot);
+            issue(2 * f + 1, tn, slot);
+            a0[f] = frag(slot ^ 1, fa, f >> 1, 0, f & 1);
+            b0[f] = frag(slot ^ 1, fb, f >> 1, 0, f & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[f >> 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[f], b1[j * 2 + (f & 1)], acc[f >> 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // epilogue: a 32 x 32 accumulator tile: lane -> column l31, register e -> row (e / 4) * 8 + hi * 4 + e % 4
+    float* slab = reinterpret_cast<float*>(smem + wave * (32 * 128 * 4));  // [32 rows][128 columns] f32 per wave
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((e >> 2) * 8 + hi * 4 + (e & 3)) * 128 + j * 32 + l31] = acc[ti][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < 32 * 128 / 8; idx += 64) {
+            const int r = idx >> 4, c8 = (idx & 15) * 8;
+            const float* sp = slab + r * 128 + c8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)sp[e];
+            *reinterpret_cast<bf16x8*>(C + (int64_t)(m0 + wm * 128 + ti * 32 + r) * N + n0 + wn * 128 + c8) = o;
+        }
+    }
+}
+
 // The transpose-read form (weight gradients): C[M][N] = A^T B with A stored [K][M], B stored [K][N].  LDS image of an operand tile
 // = [64 k-rows][256 columns] (512-B rows), 2 k-rows per DMA piece, 16-B slot s of row r holding source chunk s ^ (key(r) << 1),
 // key(r) = (r & 3) | (((r >> 3) & 1) << 2); fragments by ds_read_b64_tr_b16 (two per 16 x 32 operand), as in the production kernel.
@@ -308,9 +421,12 @@ int main() {
         CK(hipFuncSetAttribute((const void*)gemm_w4<384>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 384) * 128));
         auto prod = [&](int persist) { kai0_gemm_set_persist(persist); return timeit([&] { if (kai0_gemm_bf16(&d, nullptr)) { printf("gemm: %s\n", kai0_last_error()); exit(1); } }); };
         auto w256 = [&] { return timeit([&] { hipLaunchKernelGGL(gemm_w4<256>, dim3((M / 256) * (N / 256)), dim3(256), 2 * 512 * 128, 0, dA, dB, dC, M, N, K, M / 256, N / 256); }); };
+        CK(hipFuncSetAttribute((const void*)gemm_w4_m32, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        auto wm32 = [&] { return timeit([&] { hipLaunchKernelGGL(gemm_w4_m32, dim3((M / 256) * (N / 256)), dim3(256), 131072, 0, dA, dB, dC, M, N, K, M / 256, N / 256); }); };
         auto w384 = [&] { return timeit([&] { hipLaunchKernelGGL(gemm_w4<384>, dim3((M / 256) * (N / 384)), dim3(256), 2 * 640 * 128, 0, dA, dB, dC, M, N, K, M / 256, N / 384); }); };
         prod(0);  // clock ramp
-        double r[2][4];
+        double r[2][4], r32[2];
+        size_t bad32 = 0;
         std::vector<uint16_t> hC((size_t)M * N), hR((size_t)M * N);
         size_t bad[2] = {0, 0};
         for (int pass = 0; pass < 2; ++pass) {
@@ -323,6 +439,12 @@ int main() {
                 CK(hipMemcpy(hR.data(), dR, hR.size() * 2, hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < hC.size(); ++i) bad[0] += hC[i] != hR[i];
             }
+            r32[pass] = wm32();
+            if (pass == 0) {
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < hC.size(); ++i) bad32 += hC[i] != hR[i];
+            }
             r[pass][3] = w384();
             if (pass == 0) {
                 CK(hipDeviceSynchronize());
@@ -332,6 +454,7 @@ int main() {
         }
         kai0_gemm_set_persist(1);
         CK(hipGetLastError());
+        printf("   4 waves 256x256 on 32x32x16 MFMAs %6.0f %6.0f (mismatches %zu)\n", r32[0], r32[1], bad32);
         printf("%6d x %6d x %6d TFLOP/s (two passes): production plain %6.0f %6.0f  persistent %6.0f %6.0f | 4 waves 256x256 %6.0f %6.0f (mismatches %zu)  256x384 %6.0f %6.0f (mismatches %zu)\n",
                M, N, K, r[0][0], r[1][0], r[0][1], r[1][1], r[0][2], r[1][2], bad[0], r[0][3], r[1][3], bad[1]);
         fflush(stdout);
