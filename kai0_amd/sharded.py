@@ -665,7 +665,7 @@ class ShardedDataParallel:
     def _update_bucket(self, b: _Bucket, lr: float, coef):
         kw = dict(lr=lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self.step_count, clip_coef=coef)
         segs = []
-        if self._sparse_rows and hasattr(self.ops, "adamw_rows") and self.device.type == "cuda":
+        if self._sparse_rows and hasattr(self.ops, "adamw_rows"):
             from .optim import sparse_rows_ok
 
             if sparse_rows_ok(lr, self.wd):  # an idle row must be a fixed point of the update (1 - lr*wd rounds to 1)

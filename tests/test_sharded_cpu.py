@@ -560,3 +560,80 @@ def test_tiny_trainer_at_world_8(mode, rs_algo):
     """Eight gloo ranks (the node's size): the tiny model through Trainer.train_step in both modes / both reduce-scatter algorithms;
     the replicas hold identical weights afterwards."""
     _spawn(_worker_world8, 8, mode, rs_algo)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+class TorchRowOps(TorchShardOps):
+    """+ the row-sparse update (kai0_adamw_rows): rows with zero moments and a zero gradient are skipped, the others go through adamw."""
+
+    calls = 0
+
+    def adamw_rows(self, master, m, v, grad, param, row_len, row_active, **kw):
+        TorchRowOps.calls += 1
+        rows = master.numel() // row_len
+        g = grad.view(rows, row_len)
+        nz = (g.float() != 0).any(1)
+        row_active |= nz.to(torch.uint8)
+        for r in torch.nonzero(row_active).flatten().tolist():
+            sl = slice(r * row_len, (r + 1) * row_len)
+            self.adamw(master[sl], m[sl], v[sl], grad[sl], param[sl], **kw)
+
+
+class _Embed(torch.nn.Module):
+    def __init__(self, rows, dim, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.pre = torch.nn.Parameter(torch.randn(13, 8, generator=g).to(torch.bfloat16))           # shifts the table off a round offset
+        self.table = torch.nn.Parameter((torch.randn(rows, dim, generator=g) * 0.05).to(torch.bfloat16))
+        self.post = torch.nn.Parameter(torch.randn(dim, 4, generator=g).to(torch.bfloat16))
+
+    def forward(self, tok):
+        return (self.table[tok].float() @ self.post.float()).sum() + self.pre.float().sum() * 1e-3
+
+
+def _sparse_rows_worker(rank, world, port, tmp):
+    from kai0_amd.sharded import ShardedDataParallel
+
+    _init(rank, world, port)
+    rows, dim = 1500, 72  # 72-element rows: the shard boundary (numel / world, 256-aligned) cuts through a row
+    res = {}
+    for sparse in (True, False):
+        model = _Embed(rows, dim, seed=3)
+        model.table._kai0_grad_accumulates = True
+        eng = ShardedDataParallel(list(model.named_parameters()), world_size=world, rank=rank, ops=TorchRowOps(), weight_decay=1e-10,
+                                  bucket_bytes=1 << 30)
+        eng._sparse_rows = sparse
+        TorchRowOps.calls = 0
+        g = torch.Generator().manual_seed(100 + rank)
+        for step in range(4):
+            eng.begin_step()
+            eng.wait_params()
+            tok = torch.randint(0, rows, (20 + 5 * step,), generator=g)
+            model(tok).backward()
+            eng.step(2.5e-5)
+        eng.wait_params()
+        if sparse:
+            b = eng.buckets[0]
+            segs = eng._sparse_segments(b)
+            assert TorchRowOps.calls >= 4 and len(segs) == 1
+            first, nrows, rl, active = segs[0]
+            o = b.offsets[next(i for i, q in enumerate(b.params) if q is model.table)]
+            lo, hi = max(o, b.lo), min(o + model.table.numel(), b.lo + b.shard)
+            assert rl == dim and (first + b.lo - o) % dim == 0 and first + b.lo >= lo and first + nrows * dim + b.lo <= hi
+            assert (lo - o) % dim != 0 or (hi - o) % dim != 0 or world == 1  # (a row IS cut on at least one side: the edges go dense)
+            assert 0 < int(active.sum()) < nrows  # some rows were touched, most never
+        else:
+            assert TorchRowOps.calls == 0
+        res[sparse] = ([p.detach().clone() for p in model.parameters()], [b.master.clone() for b in eng.buckets],
+                       [b.exp_avg.clone() for b in eng.buckets], [b.exp_avg_sq.clone() for b in eng.buckets])
+    for a, b in zip(res[True], res[False]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    _done(rank, tmp)
+
+
+def test_row_sparse_embedding_update_equals_the_dense_one_across_shard_boundaries():
+    """sharded._update_bucket: whole rows of a scatter-gradient table inside this rank's shard go through `adamw_rows`, what a shard
+    boundary cuts off goes through `adamw`; parameters, masters and moments after 4 steps are identical to the all-dense update on
+    both ranks."""
+    _spawn(_sparse_rows_worker, 2)
