@@ -464,8 +464,8 @@ int kai0_add_f32(const float* a, const float* b, float* out, int64_t n, kai0_str
 /* dst[C][R] = src[R][C]^T (bf16, R and C multiples of 8).  Used to turn dgrad (dx = dy W) into the faster
  * K-contiguous GEMM form: W^T is 0.2 % of the bytes the GEMM streams when M = B*S is large. */
 int kai0_transpose_bf16(const void* src, void* dst, int R, int C, kai0_stream_t stream);
-/* Sampled content checksum: out_dev[0] += sum over every `stride`-th 16-byte chunk (position-mixed) of the n buffers listed in the
- * DEVICE array items_dev (pointers 16-byte aligned, nbytes >= 16).  out_dev is zeroed by the caller.  The inference engine stamps
+/* Sampled content checksum: out_dev[0] += sum over every `stride`-th 64-byte unit (position-mixed) of the n buffers listed in the
+ * DEVICE array items_dev (pointers 16-byte aligned, nbytes >= 64).  out_dev is zeroed by the caller.  The inference engine stamps
  * the source tensors of its derived weight copies with it once per action chunk, to notice in-place weight edits that bypass
  * autograd's version counters (the engine-invalidation contract of INTEGRATION.md, now checked). */
 typedef struct kai0_ck_item {

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     }
 }
 
-// Sampled content checksum of a list of buffers (device array of {pointer, bytes}): every `stride`-th 16-byte chunk of each buffer,
+// Sampled content checksum of a list of buffers (device array of {pointer, bytes}): every `stride`-th 64-byte unit of each buffer,
 // mixed with its position, summed into one 64-bit integer (integer addition: order-free, hence deterministic).  The inference engine
 // stamps the tensors its derived weight copies were cut from with it at the end of every action chunk, so that an in-place edit
 // of a weight that bypasses autograd's version counters (`p.data.mul_()`, a foreign kernel) is noticed (infer.py `_content_ok`).
@@ -529,14 +529,15 @@ __global__ __launch_bounds__(256) void sampled_checksum_kernel(const kai0_ck_ite
     unsigned long long acc = 0;
     for (int it = blockIdx.y; it < n; it += gridDim.y) {
         const kai0_ck_item item = items[it];
-        const int64_t chunks = item.nbytes >> 4;
-        const int64_t ns = (chunks + stride - 1) / stride;
+        const int64_t units = item.nbytes >> 6;  // 64-byte units: four adjacent lanes read one (a first version read lone 16-B chunks 512 B
+        const int64_t ns = (units + stride - 1) / stride;  // apart — a cache line per 16 bytes — and took 88 us per action chunk)
         const uint4* base = reinterpret_cast<const uint4*>(item.ptr);
-        for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < ns; k += (int64_t)gridDim.x * 256) {
-            int64_t c = k * stride + ((it * 7 + k) % stride);  // (a different phase per sample: no fixed column is blind)
-            if (c >= chunks) c = chunks - 1;
-            const uint4 u = base[c];
-            const unsigned long long lo = ((unsigned long long)u.y << 32) | u.x, hi = ((unsigned long long)u.w << 32) | u.z;
+        for (int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; k < ns; k += (int64_t)gridDim.x * 64) {
+            int64_t u = k * stride + ((it * 7 + k) % stride);  // (a different phase per sample: no fixed offset is blind)
+            if (u >= units) u = units - 1;
+            const int64_t c = u * 4 + (threadIdx.x & 3);
+            const uint4 w = base[c];
+            const unsigned long long lo = ((unsigned long long)w.y << 32) | w.x, hi = ((unsigned long long)w.w << 32) | w.z;
             acc += (lo ^ (hi * 0x9E3779B97F4A7C15ull)) * (2ull * (unsigned long long)(c + it) + 1ull);
         }
     }
@@ -864,7 +865,7 @@ KAI0_API int kai0_pack_rows(const kai0_pack_part* parts, int n, const int32_t* p
 }
 KAI0_API int kai0_sampled_checksum(const kai0_ck_item* items_dev, int n, int stride, unsigned long long* out_dev, kai0_stream_t stream) {
     KAI0_REQUIRE(items_dev != nullptr && out_dev != nullptr && n > 0 && stride > 0, "kai0_sampled_checksum: empty");
-    hipLaunchKernelGGL(sampled_checksum_kernel, dim3(8, n < 512 ? n : 512), dim3(256), 0, S_(stream), items_dev, n, stride, out_dev);
+    hipLaunchKernelGGL(sampled_checksum_kernel, dim3(2, n < 512 ? n : 512), dim3(256), 0, S_(stream), items_dev, n, stride, out_dev);
     return kai0_check_launch("kai0_sampled_checksum");
 }
 KAI0_API int kai0_transpose_bf16(const void* src, void* dst, int R, int C, kai0_stream_t stream) {

@@ -108,7 +108,7 @@ class InferenceEngine:
                 and self._content_ok())  # fmt: skip
 
     # ---- content stamp of the source weights (the engine-invalidation contract, checked) ------------------------------------
-    _CK_STRIDE = 32  # every 32nd 16-byte chunk: ~30 MB of the ~1 GB the derived copies were cut from, a few microseconds
+    _CK_STRIDE = 128  # every 128th 64-byte unit: ~8 MB of the ~1 GB the derived copies were cut from, a few microseconds
 
     def _content_init(self):
         """The tensors of `_fingerprint` are also summed by content (kai0_sampled_checksum) at the end of every action chunk, inside
@@ -121,7 +121,7 @@ class InferenceEngine:
         self._ck_on = os.environ.get("KAI0_INFER_CHECKSUM", "1") != "0" and self.dev.type == "cuda"
         if not self._ck_on:
             return
-        srcs = [p for p in self._fp_srcs if p.numel() * p.element_size() >= 16 and p.data_ptr() % 16 == 0 and p.is_contiguous()]
+        srcs = [p for p in self._fp_srcs if p.numel() * p.element_size() >= 64 and p.data_ptr() % 16 == 0 and p.is_contiguous()]
         self._ck_items = torch.tensor([[p.data_ptr(), p.numel() * p.element_size()] for p in srcs], dtype=torch.int64).to(self.dev)
         self._ck_n = len(srcs)
         self._ck_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
