@@ -51,7 +51,10 @@ int kai0_device_info(int device, int* n_cu, int* lds_bytes, char* arch_name64);
  * and to the output row (C, pre_out and residual share c_*).
  *
  * Batching: grid z in [0,batch): z1 = z / batch_inner, z2 = z % batch_inner; operand X is offset by
- * z1*sX1 + z2*sX2 elements.
+ * z1*sX1 + z2*sX2 elements.  The strides are SIGNED 64-bit element counts added to the base pointer in 64-bit arithmetic:
+ * a stride may be negative, and it may be the distance between two separate allocations (the joint-attention backward runs
+ * dV = P^T dO and dK = dS^T Q as one launch whose outer B stride is `&Q - &dO`), as long as every entry z addresses valid,
+ * 16-B aligned memory — multiples of 8 elements are required (checked), the range is the caller's responsibility.
  *
  * Epilogue, in this order, on the f32 accumulator v (every step that the reference performs as a bf16
  * torch op rounds to bf16 exactly there):

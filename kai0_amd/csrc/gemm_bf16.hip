@@ -1628,6 +1628,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
                  d->M);
     KAI0_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
                  "kai0_gemm_bf16: operands must be 16-byte aligned");
+    // batch strides: signed element counts, may be negative or span two allocations (kai0hip.h); every entry must stay 16-B aligned
+    KAI0_REQUIRE(d->batch <= 1 || (((d->sA1 | d->sA2 | d->sB1 | d->sB2) & 7) == 0 && ((d->sC1 | d->sC2) & (d->out_f32 ? 3 : 7)) == 0),
+                 "kai0_gemm_bf16: batch strides must be multiples of 8 elements (16 B)");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
     KAI0_REQUIRE(d->act >= 0 && d->act <= 6, "kai0_gemm_bf16: unknown act %d", d->act);
     KAI0_REQUIRE(d->act != 6 || (d->B2 && d->a_kc && d->b_kc && d->batch <= 1 && d->split_k <= 1 && !d->out_f32 && !d->accumulate &&

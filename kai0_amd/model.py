@@ -700,6 +700,9 @@ class PI0Pytorch(nn.Module):
         eng = self._engine
         if eng is not None and eng.stale():  # weights edited in place behind autograd's back: every cached engine holds old copies
             self._engine = eng = None
+            # ... the other prompt-length buckets' engines too: their own stamps still equal their reference (they have not run since
+            # the edit), so `compatible()` would accept them and the next request in their bucket would compute from old weights
+            self.__dict__.pop("_engine_lru", None)
         if eng is None or not eng.compatible(*key):
             lru = self.__dict__.setdefault("_engine_lru", {})
             eng = lru.pop(key, None)

@@ -1162,7 +1162,7 @@ class EmbedFn(torch.autograd.Function):
         V, D = ctx.shape
         dst = getattr(ctx.table, "_kai0_grad_out", None)
         if dst is not None and dst.shape == (V, D) and dst.dtype == BF16:
-            dtable = dst  # pre-zeroed slice of the trainer's flat gradient buffer
+            dtable = _grad_dst(ctx.table, BF16)  # pre-zeroed slice of the trainer's flat gradient buffer (fsdp: storage ensured first)
             ctx.table._kai0_grad_accumulates = True  # the scatter-add needs it zeroed again before the next backward
         else:
             dtable = torch.zeros((V, D), dtype=BF16, device=dout.device)

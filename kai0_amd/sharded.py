@@ -448,7 +448,15 @@ class ShardedDataParallel:
                 b.rs_work = None
             if b.arrived or b.pending != len(b.params):
                 if b.grad_resident:  # the aborted step's partial gradients must not be taken for this step's
-                    b.stale.update(b.arrived)
+                    for p, o in zip(b.params, b.offsets):
+                        if id(p) not in b.arrived:
+                            continue
+                        if getattr(p, "_kai0_grad_accumulates", False):
+                            # a producer that scatter-ADDS into a slice it assumes zero (the embedding table): "stale" would only
+                            # re-zero it when no new gradient arrives — the aborted gradient would be added to the new one
+                            b.flat_grad[o : o + p.numel()].zero_()
+                        else:
+                            b.stale.add(id(p))
                 b.arrived.clear()
                 b.pending = len(b.params)
             b.announced = False
@@ -670,6 +678,11 @@ class ShardedDataParallel:
 
             if sparse_rows_ok(lr, self.wd):  # an idle row must be a fixed point of the update (1 - lr*wd rounds to 1)
                 segs = self._sparse_segments(b)
+        if not segs:
+            # dense pass over the whole shard: rows first touched here get nonzero moments WITHOUT their activity flag being set
+            # (only kai0_adamw_rows sets flags), so the cached flags are void — rebuilt from the moments at the next sparse step
+            # (a schedule whose lr * wd crosses the 2^-25 threshold goes sparse -> dense -> sparse)
+            b._sparse_key = None
         cur = 0
         for first, rows, rl, active in segs:
             if first > cur:

@@ -191,6 +191,28 @@ def test_gemm_row_remaps_and_batch(ops):
     assert_close_bf16(sc.view(n, NH, S, S), qh @ kh.transpose(-1, -2), what="two-level batch")
 
 
+def test_gemm_batch_strides_may_be_negative_or_span_two_allocations(ops):
+    """kai0hip.h: the batch strides are signed 64-bit element counts.  The joint-attention backward uses `&Q - &dO` — the distance
+    between two separately allocated tensors, of either sign — as the outer B stride of its merged dV | dK launch."""
+    from kai0_amd._lib import Kai0HipError
+
+    Bn, M, N, K = 2, 64, 72, 136
+    a = rnd(2 * Bn * K, M, seed=1)  # A stored [K][M] per entry (TN), entries (j, b) contiguous
+    pool = rnd(4 * Bn * K * N + 64, seed=2)  # two "allocations" cut from one pool: the test controls their order
+    lo, hi = pool[: Bn * K * N].view(Bn, K, N), pool[3 * Bn * K * N : 4 * Bn * K * N].view(Bn, K, N)
+    for b0, b1 in ((lo, hi), (hi, lo)):  # positive, then negative outer stride
+        out = torch.empty((2, Bn, M, N), dtype=BF16, device=dev())
+        dist = (b1.data_ptr() - b0.data_ptr()) // 2
+        ops.gemm(a, b0, out, M=M, N=N, K=K, a_kc=False, b_kc=False, lda=M, ldb=N, ldc=N, batch=2 * Bn, batch_inner=Bn,
+                 sA=(Bn * K * M, K * M), sB=(dist, K * N), sC=(Bn * M * N, M * N))
+        av = a.view(2, Bn, K, M).float()
+        for j, bt in enumerate((b0, b1)):
+            assert_close_bf16(out[j], av[j].transpose(-1, -2) @ bt.float(), what=f"outer stride {dist:+d}, entry {j}")
+    with pytest.raises(Kai0HipError):  # a stride that would break the 16-B alignment of an entry is refused
+        ops.gemm(a, lo, out, M=M, N=N, K=K, a_kc=False, b_kc=False, lda=M, ldb=N, ldc=N, batch=2 * Bn, batch_inner=Bn,
+                 sA=(Bn * K * M, K * M), sB=(dist + 4, K * N), sC=(Bn * M * N, M * N))
+
+
 def test_gemm_n_not_multiple_of_8(ops):
     M, N, K, ld = 64, 20, 72, 24
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)

@@ -637,3 +637,75 @@ def test_row_sparse_embedding_update_equals_the_dense_one_across_shard_boundarie
     boundary cuts off goes through `adamw`; parameters, masters and moments after 4 steps are identical to the all-dense update on
     both ranks."""
     _spawn(_sparse_rows_worker, 2)
+
+
+def test_row_sparse_flags_are_rebuilt_after_a_dense_phase():
+    """with a weight decay large enough that lr * wd crosses the 2^-25 threshold, the schedule goes sparse (warm-up) ->
+    dense (peak) -> sparse (end_lr).  Rows first touched in the dense phase have nonzero moments but no activity flag (only
+    `adamw_rows` sets flags): the cached flags must be dropped on the dense branch, or those rows' momentum tails are skipped.
+    Trajectory identical to the all-dense engine."""
+    from kai0_amd.optim import sparse_rows_ok
+    from kai0_amd.sharded import ShardedDataParallel
+
+    rows, dim, wd = 1500, 64, 1e-2
+    lrs = [1e-7, 1e-7, 1e-4, 1e-4, 1e-7, 1e-7, 1e-7]
+    assert [sparse_rows_ok(lr, wd) for lr in lrs] == [True, True, False, False, True, True, True]
+    res = {}
+    for sparse in (True, False):
+        model = _Embed(rows, dim, seed=3)
+        model.table._kai0_grad_accumulates = True
+        eng = ShardedDataParallel(list(model.named_parameters()), world_size=1, rank=0, ops=TorchRowOps(), weight_decay=wd,
+                                  bucket_bytes=1 << 30)
+        eng._sparse_rows = sparse
+        g = torch.Generator().manual_seed(7)
+        for step, lr in enumerate(lrs):
+            eng.begin_step()
+            # disjoint token ranges per phase: the rows of steps 2-3 are touched ONLY while the update is dense
+            tok = torch.randint(200 * step, 200 * (step + 1), (30,), generator=g)
+            model(tok).backward()
+            eng.step(lr)
+        res[sparse] = ([p.detach().clone() for p in model.parameters()], [b.master.clone() for b in eng.buckets],
+                       [b.exp_avg.clone() for b in eng.buckets], [b.exp_avg_sq.clone() for b in eng.buckets])
+    for a, b in zip(res[True], res[False]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_begin_step_zeroes_an_accumulating_producers_slice_after_an_aborted_backward():
+    """the embedding table's gradient is scatter-ADDED into a slice assumed zero.  After a backward that never reached
+    step() (evaluation with gradients, an exception), the next step's embedding gradient must be the new one alone — `stale` marking
+    would only re-zero the slice if NO new gradient arrived."""
+    from kai0_amd.sharded import ShardedDataParallel
+
+    class AccEmbed(torch.autograd.Function):  # writes like ops.EmbedFn.backward: += into p._kai0_grad_out, then reports arrival
+        @staticmethod
+        def forward(ctx, table, tok):
+            ctx.table, ctx.tok = table, tok
+            return table.detach()[tok].float()
+
+        @staticmethod
+        def backward(ctx, gy):
+            t = ctx.table
+            t._kai0_grad_out.index_add_(0, ctx.tok, gy.to(t.dtype))
+            t._kai0_grad_done()
+            return None, None
+
+    def run(abort: bool):
+        model = _Embed(300, 16, seed=5)
+        model.table._kai0_grad_accumulates = True
+        eng = ShardedDataParallel(list(model.named_parameters()), world_size=1, rank=0, ops=TorchShardOps(), weight_decay=0.0,
+                                  max_grad_norm=None, bucket_bytes=1 << 30)
+        tok = torch.tensor([3, 7, 7, 250])
+        loss = lambda scale: ((AccEmbed.apply(model.table, tok) @ model.post.float()).sum() * scale  # noqa: E731
+                              + model.pre.float().sum() * 1e-3)
+        if abort:
+            eng.begin_step()
+            loss(5.0).backward()  # never reaches step()
+        eng.begin_step()
+        loss(1.0).backward()
+        b = eng.buckets[0]
+        o = b.offsets[next(i for i, q in enumerate(b.params) if q is model.table)]
+        return b.flat_grad[o : o + model.table.numel()].clone()
+
+    clean, aborted = run(False), run(True)
+    assert float(clean.abs().sum()) > 0 and torch.equal(clean, aborted)
