@@ -1,0 +1,263 @@
+"""Parity AT THE CONFIGURATION THE DRIVER TIMES (VERDICT r4 "next round" #1): BASELINE.json configs[1] — the full pi0.5 (18 joint
+Gemma-2B / 300M-expert layers, 27 SigLIP layers, full widths, vocab 257 152 with the tied lm_head and the dead expert lm_head),
+three 224^2 cameras, 200 prompt slots, 50 x 32 actions, **B = 32 under `Trainer`** exactly as `bench.py` builds it (zero2 engine on
+one GPU, in-place flat gradients, second stream for the action expert, persistent NT kernel / 256^2 quadrant / TN ring / act-6
+schedules picked by shape, `kai0_adamw_rows` for the embedding table).  Every earlier full-depth comparison ran at B = 1 or 2 and
+vocab 2048; the launches that only exist at M = 30 976 were covered as isolated kernels.
+
+  (a) the B = 32 loss rows and every parameter gradient of mean(loss) against the SAME 32 samples run one at a time through the
+      B = 1 HIP path (which tests/test_fulldepth_gpu.py pins to the fp32 and bf16 oracles at this depth): loss rows rel-L2 <= 1e-2
+      each, every gradient within 5e-2 rel-L2 of the f32 mean of the 32 single-sample gradients (the flat bound the B = 1 path meets
+      against fp32 autograd; both sides here are bf16 paths, measured figures are written to the report);
+  (a') the fp32 oracle (full vocab, identical weights) on samples 0 and 17 of the batch: loss rows <= 1e-2;
+  (b) two optimizer steps of that Trainer with prompt token ids drawn from the WHOLE vocabulary (ids far above 2048): the embedding
+      rows a step touches against `torch.optim.AdamW(betas 0.9 / 0.95, eps 1e-8, wd 1e-10)` fed the same clipped gradients (f32
+      masters within 1e-6 absolute + 1e-5 relative, the bf16 rows within one ulp); rows never touched stay bit-identical with zero
+      moments; the engine's row-activity flags name exactly the touched rows.
+Reference: pi0_pytorch.py:316-373, train_pytorch.py:547-567, optimizer.py:15-85.  Figures -> gpurun_out/parity_r05.txt (committed as
+profiles/parity_r05.txt)."""
+
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+F32, BF16 = torch.float32, torch.bfloat16
+REPORT = os.path.join("gpurun_out", "parity_r05.txt")
+B = 32
+VOCAB = 257152
+
+
+def _report(line: str):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+    print(line)
+
+
+def grel(a, b):
+    """rel-L2 on the device (the parameters are 3.35 B elements: no host copies)"""
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _slice_obs(obs, i):
+    from kai0_amd.preprocessing import Observation
+
+    sl = slice(i, i + 1)
+    return Observation(images={k: v[sl] for k, v in obs.images.items()}, image_masks={k: v[sl] for k, v in obs.image_masks.items()},
+                       state=obs.state[sl], tokenized_prompt=obs.tokenized_prompt[sl], tokenized_prompt_mask=obs.tokenized_prompt_mask[sl])  # fmt: skip
+
+
+def _batch(cfg, seed, dev):
+    """bench.py's synthetic batch with the prompt ids drawn from the whole vocabulary, + fixed noise / time"""
+    import bench
+
+    obs, actions = bench.synthetic_batch(cfg, B, seed=seed, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed + 7)
+    obs.tokenized_prompt = torch.randint(0, VOCAB, obs.tokenized_prompt.shape, generator=g, device=dev, dtype=torch.int64)
+    obs.tokenized_prompt[:, 0] = VOCAB - 1 - torch.arange(B, device=dev)  # the table's last rows are certainly among them
+    noise = torch.randn(actions.shape, generator=g, device=dev)
+    torch.manual_seed(seed + 11)
+    tm = torch.distributions.Beta(torch.tensor(1.5), torch.tensor(1.0)).sample((B,)).to(dev) * 0.999 + 0.001
+    return obs, actions, noise, tm.to(F32)
+
+
+@pytest.fixture(scope="module")
+def bc():
+    from fulldepth import synthetic_weights_device_
+
+    from kai0_amd.config import Pi0Config
+    from kai0_amd.model import PI0Pytorch
+
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    if os.path.exists(REPORT):
+        os.remove(REPORT)
+    t0 = time.time()
+    cfg = Pi0Config()  # vocab 257 152: bench.py's configuration
+    with torch.device(dev):
+        model = PI0Pytorch(cfg)
+    synthetic_weights_device_(model, seed=0)
+    model.train_augmentation = False  # (augmentation is torch preprocessing in front of the path; off so that B = 1 and B = 32 see the same pixels)
+    model.train()
+    obs, actions, noise, tm = _batch(cfg, 1000, dev)
+    _report("# parity at the benchmarked configuration (tests/test_bench_config_gpu.py): full depth / width, vocab 257152, B = 32 under Trainer")
+    _report(f"# stored elements {sum(v.numel() for v in model.state_dict().values())}; prompt ids in [0, {VOCAB}), max id "
+            f"{int(obs.tokenized_prompt.max())}, valid tokens per sample {int(obs.tokenized_prompt_mask.sum(1).min())}-"
+            f"{int(obs.tokenized_prompt_mask.sum(1).max())}; build {time.time() - t0:.1f} s")  # fmt: skip
+    return dict(model=model, cfg=cfg, dev=dev, obs=obs, actions=actions, noise=noise, time=tm, state={})
+
+
+def test_b32_loss_and_gradients_equal_the_mean_of_32_single_sample_runs(bc):
+    from kai0_amd.train import Trainer
+
+    model, dev, obs, actions, noise, tm = bc["model"], bc["dev"], bc["obs"], bc["actions"], bc["noise"], bc["time"]
+    assert model.paligemma_with_expert.paligemma.model.language_model.embed_tokens.weight.shape[0] == VOCAB
+    # ---- 32 single-sample runs through the B = 1 path, plain autograd; gradients summed in f32 -------------------------------------
+    t0 = time.time()
+    acc = {n: torch.zeros(p.shape, dtype=F32, device=dev) for n, p in model.named_parameters()}
+    single_rows = []
+    for i in range(B):
+        li = model(_slice_obs(obs, i), actions[i : i + 1], noise=noise[i : i + 1], time=tm[i : i + 1])
+        single_rows.append(li.detach().clone())
+        (li.mean() / B).backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                acc[n] += p.grad.float()
+                p.grad = None
+    torch.cuda.synchronize()
+    t_single = time.time() - t0
+    # ---- the benchmarked step: Trainer as bench.py builds it, B = 32, gradients produced in place in the flat buffers -----------------
+    tr = Trainer(model, world_size=1, rank=0, peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000, end_lr=2.5e-6,
+                 weight_decay=1e-10, clip_norm=1.0)  # fmt: skip
+    eng = tr.engine
+    eng.begin_step()
+    t0 = time.time()
+    losses = model(obs, actions, noise=noise, time=tm)
+    losses.mean().backward()
+    torch.cuda.synchronize()
+    t_b32 = time.time() - t0
+    assert losses.shape == (B, 50, 32) and losses.dtype == F32
+    rows = [grel(losses[i : i + 1], single_rows[i]) for i in range(B)]
+    _report(f"(a) loss rows, B = 32 launch vs the same sample through the B = 1 path: worst rel-L2 {max(rows):.3e}, median "
+            f"{sorted(rows)[B // 2]:.3e}; whole tensor {grel(losses, torch.cat(single_rows)):.3e}  (32 single runs {t_single:.1f} s, B = 32 "
+            f"forward + backward incl. first-use warm-up {t_b32:.2f} s)")  # fmt: skip
+    assert max(rows) <= 1e-2
+    names = {id(p): n for n, p in model.named_parameters()}
+    table, none_both = [], 0
+    for b in eng.buckets:
+        for p, o in zip(b.params, b.offsets):
+            n = names[id(p)]
+            got = b.flat_grad[o : o + p.numel()].view(p.shape)
+            want = acc[n]
+            assert p.grad is None, n
+            wn = float(want.norm())
+            if wn < 1e-12:  # no gradient in the single runs (dead prefix tail of the last layer, language_model.norm): none here either
+                assert float(got.float().abs().max()) == 0.0, n
+                none_both += 1
+                continue
+            table.append((grel(got, want), n, wn))
+    table.sort(reverse=True)
+    bc["state"]["grad_table"] = table
+    med = table[len(table) // 2][0]
+    _report(f"(a) gradients of mean(loss), B = 32 (in-place flat buffers) vs f32 mean of 32 single-sample gradients: {len(table)} parameters, "
+            f"worst rel-L2 {table[0][0]:.3e} ({table[0][1]}), median {med:.3e}; {none_both} parameters without a gradient on both sides")  # fmt: skip
+    for r, n, wn in table[:8]:
+        _report(f"    {r:.3e}  |g|={wn:.3e}  {n}")
+    with open(os.path.join("gpurun_out", "grad_table_b32.txt"), "w") as f:
+        f.write("# rel-L2 of d mean(loss) / d parameter: B = 32 Trainer launch vs f32 mean of 32 B = 1 launches | |g| | name\n")
+        for r, n, wn in table:
+            f.write(f"{r:.3e}  |g|={wn:.3e}  {n}\n")
+    assert len(table) >= 700
+    assert table[0][0] <= 5e-2 and med <= 2e-2
+    del acc
+    bc["state"].update(trainer=tr, losses=losses.detach(), pending_step=True)
+
+
+def test_b32_loss_rows_match_the_fp32_oracle_on_two_samples(bc):
+    """Two of the 32 samples through the fp32 oracle with the SAME weights (full vocabulary: ids above 2048 index the real table)."""
+    from fulldepth import host_state
+    from oracle import pi0_oracle as O
+
+    if "losses" not in bc["state"]:
+        pytest.skip("needs the B = 32 launch of the previous test")
+    model, obs = bc["model"], bc["obs"]
+    t0 = time.time()
+    state = host_state(model)
+    cfg = O.OracleConfig(dtype="float32", vocab_size=VOCAB)
+    with torch.device("meta"):
+        o32 = O.OraclePI0(cfg)
+    o32.to_empty(device="cpu")
+    with torch.no_grad():
+        o32.load_state_dict(state, strict=True)
+        for mod in o32.modules():
+            if isinstance(getattr(mod, "inv_freq", None), torch.Tensor):
+                mod.inv_freq = O.rope_inv_freq(mod.inv_freq.numel() * 2).to(BF16).float()
+            if isinstance(mod, O.SiglipVisionEmbeddings):
+                mod.position_ids = torch.arange(mod.num_patches).expand((1, -1))
+    del state
+    pick = [0, 17]
+    cobs = O.SimpleObs(images={k: v[pick].cpu() for k, v in obs.images.items()}, image_masks={k: v[pick].cpu() for k, v in obs.image_masks.items()},
+                       state=obs.state[pick].cpu(), tokenized_prompt=obs.tokenized_prompt[pick].cpu(),
+                       tokenized_prompt_mask=obs.tokenized_prompt_mask[pick].cpu(), token_ar_mask=None, token_loss_mask=None)  # fmt: skip
+    t1 = time.time()
+    with torch.no_grad():
+        ref = o32(cobs, bc["actions"][pick].cpu(), bc["noise"][pick].cpu(), bc["time"][pick].cpu())
+    got = bc["state"]["losses"][pick].cpu()
+    rs = [float((got[j] - ref[j]).norm() / ref[j].norm()) for j in range(2)]
+    _report(f"(a') loss rows of samples {pick} of the B = 32 launch vs the fp32 oracle (vocab {VOCAB}, token ids up to "
+            f"{int(cobs.tokenized_prompt.max())}): rel-L2 {rs[0]:.3e} / {rs[1]:.3e}  (oracle build {t1 - t0:.1f} s, forward {time.time() - t1:.1f} s)")  # fmt: skip
+    assert max(rs) <= 1e-2
+    del o32
+
+
+def test_two_trainer_steps_at_full_vocab_match_torch_adamw_on_the_touched_rows(bc):
+    from kai0_amd.optim import lr_schedule
+
+    st = bc["state"]
+    if "trainer" not in st:
+        pytest.skip("needs the Trainer of the first test")
+    model, dev, tr = bc["model"], bc["dev"], st["trainer"]
+    eng = tr.engine
+    table = model.paligemma_with_expert.paligemma.model.language_model.embed_tokens.weight
+    b, o = eng._where[table]
+    rl = table.shape[1]
+    gview = b.flat_grad[o : o + table.numel()].view(table.shape)
+    mview = lambda t: t[o - b.lo : o - b.lo + table.numel()].view(table.shape)  # noqa: E731 - one GPU: the shard is the whole buffer
+    assert b.lo == 0 and b.shard == b.numel
+    w0 = table.detach().clone()
+    batches = [(bc["obs"], bc["actions"], bc["noise"], bc["time"]), _batch(bc["cfg"], 2000, dev)]
+    # step 2's prompts reuse some of step 1's ids (their moments continue) next to new ones
+    batches[1][0].tokenized_prompt[:, :40] = bc["obs"].tokenized_prompt[:, :40]
+    touched = torch.unique(torch.cat([bt[0].tokenized_prompt.reshape(-1) for bt in batches]))
+    assert int(touched.max()) == VOCAB - 1 and int((touched >= 2048).sum()) > 1000
+    ref_p = torch.nn.Parameter(w0[touched].float())
+    ropt = torch.optim.AdamW([ref_p], lr=1.0, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-10)
+    sched = dict(peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000, end_lr=2.5e-6)
+    for step, (obs, actions, noise, tm) in enumerate(batches):
+        if not (step == 0 and st.pop("pending_step", False)):  # (step 0's backward already ran in the first test: same batch)
+            eng.begin_step()
+            model(obs, actions, noise=noise, time=tm).mean().backward()
+        g_rows = gview[touched].float()  # this step's embedding gradient, before the optimizer consumes it
+        used = torch.unique(obs.tokenized_prompt[obs.tokenized_prompt_mask])
+        nz = (gview != 0).any(1)
+        assert int(nz.sum()) <= used.numel() and bool(nz[used].float().mean() > 0.99)  # gradient rows = the valid prompt tokens' rows
+        lr = lr_schedule(tr.global_step, **sched)
+        norm = eng.step(lr)
+        tr.global_step += 1
+        coef = min(1.0, 1.0 / (float(norm) + 1e-6))
+        for gr in ropt.param_groups:
+            gr["lr"] = lr
+        ref_p.grad = g_rows * coef
+        ropt.step()
+        eng.wait_params()
+        torch.cuda.synchronize()
+        master = mview(b.master)[touched]
+        d_abs = float((master - ref_p.detach()).abs().max())
+        upd = float((ref_p.detach() - w0[touched].float()).abs().max())
+        ok = torch.isclose(master, ref_p.detach(), rtol=1e-5, atol=1e-6)
+        ulp = (table.detach()[touched].view(torch.int16).int() - ref_p.detach().to(BF16).view(torch.int16).int()).abs()
+        _report(f"(b) step {step + 1}: lr {lr:.3e}, |g| {float(norm):.4f}, clip {coef:.4f}; {touched.numel()} touched embedding rows ({int((touched >= 2048).sum())} with "
+                f"id >= 2048): f32 master vs torch.optim.AdamW max |d| {d_abs:.2e} (largest update {upd:.2e}), bf16 rows differing by one ulp "
+                f"{float((ulp == 1).float().mean()):.2e}, by more {int((ulp > 1).sum())}")  # fmt: skip
+        assert bool(ok.all()) and int((ulp > 1).sum()) == 0 and float((ulp == 1).float().mean()) < 1e-3
+    # rows no step touched: bit-identical weights, zero moments, flagged idle
+    idle = torch.ones(VOCAB, dtype=torch.bool, device=dev)
+    idle[touched] = False
+    assert torch.equal(table.detach()[idle], w0[idle])
+    assert not bool(mview(b.exp_avg)[idle].any()) and not bool(mview(b.exp_avg_sq)[idle].any())
+    segs = eng._sparse_segments(b)
+    assert len(segs) == 1, "the embedding table must go through kai0_adamw_rows in the benchmarked configuration"
+    first, nrows, srl, active = segs[0]
+    assert first == o and nrows == VOCAB and srl == rl
+    valid_rows = torch.unique(torch.cat([bt[0].tokenized_prompt[bt[0].tokenized_prompt_mask] for bt in batches]))
+    assert int(active.sum()) == valid_rows.numel() and bool(active[valid_rows].all())
+    _report(f"(b) {int(idle.sum())} untouched rows bit-identical with zero moments; activity flags = the {valid_rows.numel()} rows of valid prompt tokens")
