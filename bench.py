@@ -86,15 +86,22 @@ def build_model(cfg, device, seed: int):
 
 
 class GemmTimer:
-    """Brackets every kai0_gemm_bf16 launch with HIP events on the launch stream (torch's current stream)."""
+    """Brackets every kai0_gemm_bf16 launch — and every attention-kernel launch (`_lib.call` of the attention entry points) — with
+    HIP events on the launch stream (torch's current stream)."""
+
+    ATTN_ENTRY = {"kai0_attn_fwd": "joint_attention_kernels", "kai0_attn_bwd_dq2": "joint_attention_kernels",
+                  "kai0_attn_bwd_dq": "joint_attention_kernels", "kai0_siglip_attn_fwd": "siglip_attention_kernels",
+                  "kai0_siglip_attn_bwd2": "siglip_attention_kernels", "kai0_siglip_attn_bwd": "siglip_attention_kernels"}  # fmt: skip
 
     def __init__(self):
         self.events = []
+        self.kernel_events = []
 
     def install(self):
-        from kai0_amd import ops
+        from kai0_amd import _lib, ops
 
         self._orig = ops.gemm
+        self._orig_call = _lib.call
         timer = self
 
         def timed_gemm(A, B, out, **kw):
@@ -108,12 +115,26 @@ class GemmTimer:
                                  (int(kw.get("a_kc", True)), int(kw.get("b_kc", True)), kw["M"], kw["N"], kw["K"], kw.get("batch", 1))))
             return r
 
+        def timed_call(name, *args):
+            fam = timer.ATTN_ENTRY.get(name)
+            if fam is None:
+                return timer._orig_call(name, *args)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig_call(name, *args)
+            e.record()
+            timer.kernel_events.append((s, e, fam))
+            return r
+
         ops.gemm = timed_gemm
+        _lib.call = timed_call
 
     def uninstall(self):
-        from kai0_amd import ops
+        from kai0_amd import _lib, ops
 
         ops.gemm = self._orig
+        _lib.call = self._orig_call
 
     def summarize(self):
         ms = sum(s.elapsed_time(e) for s, e, _, _ in self.events)
@@ -130,6 +151,65 @@ class GemmTimer:
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         return [{"a_kc": k[0], "b_kc": k[1], "M": k[2], "N": k[3], "K": k[4], "batch": k[5], "calls": v[0], "ms": v[1],
                  "tflops": v[2] / v[1] / 1e9} for k, v in rows]
+
+    def families(self, batch: int, steps: int):
+        """The bf16 GEMM launches by the family north_star's targets are written in (">= 40 % MFMA on Gemma / ViT blocks"), from the
+        launch shapes: M (or, for the transposed-operand weight gradients, K) = batch x 968 prefix rows -> Gemma-2B; batch x 768
+        patch rows -> SigLIP (its projector included); batch x 50 action rows -> the 300M expert; batched launches -> the dV | dK
+        GEMM of the joint attention backward.  Per family: ms and TFLOP per step, achieved TFLOP/s, fraction of the 2.5 PFLOP/s
+        peak.  `attention` = the attention kernels' launches (kai0_attn_fwd / kai0_attn_bwd_dq2 / kai0_siglip_attn_*) + that dV | dK
+        GEMM, priced on the ALGORITHMIC attention work (4 Sq Sk heads hd per layer forward, twice that backward — the
+        recomputed logits of the backward kernel are not credited)."""
+        rows_gemma, rows_siglip, rows_expert = batch * 968, batch * 768, batch * 50
+        fam = {}
+
+        def add(name, ms, fl):
+            a = fam.setdefault(name, [0.0, 0.0, 0])
+            a[0] += ms
+            a[1] += fl
+            a[2] += 1
+
+        for s, e, f, (a_kc, b_kc, M, N, K, nb) in self.events:
+            ms = s.elapsed_time(e)
+            wgrad = not a_kc and not b_kc
+            rows = K if wgrad else M
+            if nb > 1:
+                add("attention_dv_dk_gemm", ms, f)
+            elif rows == rows_gemma:
+                add("gemma_wgrad" if wgrad else "gemma_linear", ms, f)
+            elif rows == rows_siglip:
+                add("siglip_wgrad" if wgrad else "siglip_linear", ms, f)
+            elif rows == rows_expert:
+                add("expert_wgrad" if wgrad else "expert_linear", ms, f)
+            else:
+                add("other", ms, f)
+        for s, e, name in self.kernel_events:
+            add(name, s.elapsed_time(e), 0.0)
+        out = {}
+        for k, (ms, fl, n) in fam.items():
+            out[k] = {"ms_per_step": ms / steps, "launches_per_step": n // steps}
+            if fl > 0:
+                out[k].update({"tflop_per_step": fl / steps / 1e12, "tflops": fl / 1e9 / ms, "frac": fl / 1e9 / ms / MFMA_BF16_PEAK_TFLOPS})
+        for grp, parts in (("gemma_blocks", ("gemma_linear", "gemma_wgrad")), ("vit_blocks", ("siglip_linear", "siglip_wgrad"))):
+            ms = sum(fam[p][0] for p in parts if p in fam)
+            fl = sum(fam[p][1] for p in parts if p in fam)
+            if ms > 0:
+                out[grp] = {"ms_per_step": ms / steps, "tflop_per_step": fl / steps / 1e12, "tflops": fl / 1e9 / ms,
+                            "frac": fl / 1e9 / ms / MFMA_BF16_PEAK_TFLOPS, "members": list(parts)}
+        # attention: kernels + the dV | dK GEMM, priced on algorithmic work
+        att_ms = sum(fam[k][0] for k in ("joint_attention_kernels", "attention_dv_dk_gemm") if k in fam)
+        if att_ms > 0:
+            alg = 3 * 4 * 1018 * 1018 * 2048 * 18 * batch  # forward + 2x backward, 18 layers, per step
+            out["attention"] = {"ms_per_step": att_ms / steps, "algorithmic_tflop_per_step": alg / 1e12, "tflops": alg * steps / 1e9 / att_ms,
+                                "frac": alg * steps / 1e9 / att_ms / MFMA_BF16_PEAK_TFLOPS,
+                                "members": ["joint_attention_kernels", "attention_dv_dk_gemm"],
+                                "note": "algorithmic 4 Sq Sk (heads hd) per layer forward, 8 backward; the backward kernel's recomputed logits are not credited"}
+        if "siglip_attention_kernels" in fam:
+            alg = 3 * 4 * 256 * 256 * 1152 * 27 * 3 * batch
+            ms = fam["siglip_attention_kernels"][0]
+            out["siglip_attention_kernels"].update({"algorithmic_tflop_per_step": alg / 1e12, "tflops": alg * steps / 1e9 / ms,
+                                                    "frac": alg * steps / 1e9 / ms / MFMA_BF16_PEAK_TFLOPS})
+        return out
 
 
 def _oracle_full_depth(O):
@@ -216,6 +296,9 @@ def cpu_baseline(batch: int = 32):
         "unit": "samples/s",
         "cores": cores,
         "kind": "port",
+        "vocab": int(cfg.vocab_size),
+        "vocab_note": "the oracle is timed at vocab 2048 (synthetic prompt ids < 2048): the 257152-row embedding table carries no FLOPs; its "
+                      "AdamW update (0.53 B of the 3.35 B trained parameters) is NOT in optimizer_s",
         "fwd_bwd_s_per_sample": t_fb,
         "optimizer_s": t_opt,
         "init_s": init_s,
@@ -356,8 +439,12 @@ def main():
     B = args.batch_per_gpu
     model = build_model(cfg, device, seed=0)  # same weights on every rank
     model.train()
+    # N > 1: the headline is north_star's partition — optimizer / gradients / PARAMETERS sharded ("fsdp": all-gather per unit ahead of
+    # forward and backward, reduce-scatter from inside backward); zero2 (parameters resident: the natural mode with 288 GB per GPU) is
+    # measured beside it (comm.zero2).  One GPU: nothing to shard, the engine's default.  KAI0_SHARD_MODE overrides.
+    want_mode = os.environ.get("KAI0_SHARD_MODE") or ("fsdp" if world > 1 else "zero2")
     trainer = Trainer(model, world_size=world, rank=rank, peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000,
-                      end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0)  # fmt: skip
+                      end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0, mode=want_mode)  # fmt: skip
     obs, actions = synthetic_batch(cfg, B, seed=1000 + rank, device=device)
 
     def barrier():
@@ -435,11 +522,11 @@ def main():
                                                     "RCCL_MSCCLPP_ENABLE", "KAI0_RS_ALGO") if k in os.environ},
             "measured": f"events on the compute stream around every collective wait, {timer_steps} steps after the timed region",
         }  # fmt: skip
-    # N > 1: north_star's partition ("optimizer / grad / PARAM sharded FSDP-style") measured next to the headline (zero2: optimizer and
-    # gradients sharded, the 7 GB bf16 model resident — the natural mode with 288 GB per GPU): a fresh model + Trainer(mode="fsdp"),
-    # 2 warm-up + 4 timed steps, its own exposed-communication figures.  KAI0_BENCH_FSDP=0 skips it.
-    fsdp = None
-    if comm is not None and trainer.engine.mode != "fsdp" and os.environ.get("KAI0_BENCH_FSDP", "1") != "0":
+    # N > 1: the OTHER partition measured next to the headline (headline fsdp -> zero2 beside it, and the other way round): a fresh
+    # model + Trainer(mode=other), 2 warm-up + 4 timed steps, its own exposed-communication figures.  KAI0_BENCH_FSDP=0 skips it.
+    other = None
+    other_mode = "zero2" if headline_mode == "fsdp" else "fsdp"
+    if comm is not None and os.environ.get("KAI0_BENCH_FSDP", "1") != "0":
         try:
             model.set_unit_hooks(None)
             del trainer, model
@@ -447,7 +534,7 @@ def main():
             model = build_model(cfg, device, seed=0)
             model.train()
             trainer = Trainer(model, world_size=world, rank=rank, peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000,
-                              end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0, mode="fsdp")  # fmt: skip
+                              end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0, mode=other_mode)  # fmt: skip
             eng = trainer.engine
             for _ in range(2):
                 trainer.train_step(obs, actions)
@@ -456,7 +543,7 @@ def main():
             barrier()
             tf0 = time.perf_counter()
             for _ in range(4):
-                loss = trainer.train_step(obs, actions)
+                loss2 = trainer.train_step(obs, actions)
             barrier()
             tf = (time.perf_counter() - tf0) / 4
             rep = eng.comm_report()
@@ -468,14 +555,17 @@ def main():
             else:
                 allr = [mine]
             tmax = max(float(t[0]) for t in allr)
-            fsdp = {"mode": eng.mode, "samples_per_s": B * world / tmax, "ms_per_step": tmax * 1e3, "buckets": len(eng.buckets),
-                    "prefetch": eng.prefetch, "comm_exposed_ms_per_rank": [float(t[1]) for t in allr],
-                    "bytes_per_rank_per_step": eng.comm_bytes_per_step(),
-                    "note": "fresh Trainer(mode='fsdp'): parameters sharded too, gathered two buckets ahead in forward and backward; "
-                            "4 steps after 2 warm-up steps; NOT the headline value"}
+            other = {"mode": eng.mode, "samples_per_s": B * world / tmax, "ms_per_step": tmax * 1e3, "buckets": len(eng.buckets),
+                     "prefetch": eng.prefetch, "comm_exposed_ms_per_rank": [float(t[1]) for t in allr],
+                     "bytes_per_rank_per_step": eng.comm_bytes_per_step(), "final_loss": float(loss2),
+                     "note": f"fresh Trainer(mode='{other_mode}') "
+                             + ("(parameters sharded too, gathered two buckets ahead in forward and backward)" if other_mode == "fsdp"
+                                else "(optimizer and gradients sharded, the bf16 model resident; all-gathers hidden behind the next forward)")
+                             + "; 4 steps after 2 warm-up steps; NOT the headline value"}
         except Exception as e:  # noqa: BLE001 - the headline line must still be printed
-            fsdp = {"error": f"{type(e).__name__}: {e}"}
-        comm["fsdp"] = fsdp
+            other = {"error": f"{type(e).__name__}: {e}"}
+        comm[other_mode] = other
+    fsdp = other
     # Extra (not the headline value): the same step with the prompt cut to the longest valid prompt of the batch
     # (model.trim_prompt_padding: the 200 prompt slots carry 64-128 valid tokens here; padded slots are invisible keys and unread
     # rows, loss and gradients unchanged beyond summation order — tests/test_model_gpu.py).  The headline number above computes
@@ -531,7 +621,7 @@ def main():
                 "seq_len": 968 + 50,
                 "parallelism": f"dp{world}" + ("" if world == 1 else f" ({headline_mode}: sharded optimizer/grads"
                                                 + ("/params" if headline_mode == "fsdp" else "") + ", RCCL reduce-scatter + all-gather"
-                                                + ("; fsdp = optimizer/grads/params sharded measured beside it: comm.fsdp" if fsdp else "") + ")"),
+                                                + (f"; {other_mode} measured beside it: comm.{other_mode}" if fsdp else "") + ")"),
                 "params_stored": 3.617e9,
                 "final_loss": float(loss),
             },
@@ -556,6 +646,7 @@ def main():
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": traffic.get("bytes_per_launch"),
                 "traffic_unit": "HBM-side bytes per GEMM launch (fetch + write), rocprofv3 PMC; not re-measured by this run",
+                "traffic_measured_by_this_run": False,
                 "traffic_source": traffic.get("source"),
                 "launches_per_step": n_launch // timer_steps,
                 "avg_launch_ms": gemm_ms / n_launch,
@@ -565,7 +656,13 @@ def main():
                 "gemm_tflop_per_step": gemm_flops / timer_steps / 1e12,
                 "timed": f"HIP events over {timer_steps} further identical steps right after the timed region, with the second "
                          "(action-expert) stream off so that every launch owns the chip while it is timed",
+                "frac_timed_inside_timed_region": False,
+                "frac_timed_steps": timer_steps,
+                "frac_timed_expert_stream": False,
                 "step_frac_of_mfma_peak": TRAIN_TFLOP_NEEDED_PER_SAMPLE * B / (ms_per_step / 1e3) / MFMA_BF16_PEAK_TFLOPS,
+                "step_frac_priced_on_tflop_per_sample": TRAIN_TFLOP_NEEDED_PER_SAMPLE,
+                "families": timer.families(B, timer_steps),
+                "targets": {"gemma_blocks_frac": 0.40, "vit_blocks_frac": 0.40},
             }
             if os.environ.get("KAI0_GEMM_BREAKDOWN"):
                 os.makedirs("gpurun_out", exist_ok=True)
