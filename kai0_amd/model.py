@@ -542,7 +542,16 @@ class PI0Pytorch(nn.Module):
         vt = pe.paligemma.model.vision_tower.vision_model
         lm, ex = pe.paligemma.model.language_model, pe.gemma_expert.model
         units = [("siglip.embed", list(vt.embeddings.parameters()))]
-        units += [(f"siglip.{l}", list(layer.parameters())) for l, layer in enumerate(vt.encoder.layers)]
+        def siglip_layer(layer):
+            # q | k | v weights (and biases) back to back in that order: the trainer's flat buffers then hold the STACKED projection
+            # weight / bias / gradient of ops.linear_multi as views (ops._as_rows) — HF's registration order is k, v, q with the
+            # biases in between, which cost two concatenations per layer and forward and three gradient copies per backward
+            at = layer.self_attn
+            first = [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias]
+            ids = {id(p) for p in first}
+            return first + [p for p in layer.parameters() if id(p) not in ids]
+
+        units += [(f"siglip.{l}", siglip_layer(layer)) for l, layer in enumerate(vt.encoder.layers)]
         units.append(("prefix", [*vt.post_layernorm.parameters(), *pe.paligemma.model.multi_modal_projector.parameters(),
                                  lm.embed_tokens.weight, *self.action_in_proj.parameters(), *self.time_mlp_in.parameters(),
                                  *self.time_mlp_out.parameters()]))  # fmt: skip

@@ -603,7 +603,11 @@ class LinearMultiFn(torch.autograd.Function):
         wcat = _as_rows([w.detach() for w in ws])
         if wcat is None:
             wcat = torch.cat(ws, dim=0)
-        bcat = torch.cat(bs, dim=0) if all(has_b) else None
+        bcat = None
+        if all(has_b):
+            bcat = _as_rows([b.detach() for b in bs])
+            if bcat is None:
+                bcat = torch.cat(bs, dim=0)
         outs = tuple(torch.empty((M, w), dtype=BF16, device=x.device) for w in widths)
         segs, c = [], 0
         for o, w in zip(outs, widths):

@@ -2,7 +2,7 @@
 # round 5, first GPU call: the new bench-configuration parity tests + the new kernel test + a short bench with the family-resolved roofline
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_bench_config_gpu.py "tests/test_kernels_gpu.py::test_gemm_batch_strides_may_be_negative_or_span_two_allocations" tests/test_kernels_gpu.py::test_gemm_row_remaps_and_batch -m gpu -q -x -s > gpurun_out/pytest_r5a.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_r5a.log
+timeout 900 python -m pytest tests/test_bench_config_gpu.py "tests/test_kernels_gpu.py::test_gemm_batch_strides_may_be_negative_or_span_two_allocations" tests/test_kernels_gpu.py::test_gemm_row_remaps_and_batch -m gpu -q -s > gpurun_out/pytest_r5a.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_r5a.log
 KAI0_GEMM_BREAKDOWN=1 timeout 900 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/bench_r5a.log 2>&1; echo "bench rc=$?"
 python - <<'PY'
 import json
