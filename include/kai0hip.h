@@ -154,10 +154,6 @@ int kai0_gemm_set_cfg(int cfg);
  * a fused GeGLU / GELU epilogue or K <= 2048 (default; env KAI0_GEMM_PERSIST), 2 = every eligible NT launch.  Results are bit-identical
  * to the one-block-per-tile launches.  Returns the previous mode. */
 int kai0_gemm_set_persist(int mode);
-/* Register-staged K loop of the 128 x 128 configuration for launches of at most one block per CU (the B = 1 inference GEMMs): operands
- * go HBM -> VGPRs (16-B buffer loads, three K-tiles in flight) -> LDS instead of by LDS-DMA; bit-identical results.  1 = on (default;
- * env KAI0_GEMM_REGSTAGE), 0 = the four-stage LDS-DMA loop.  Returns the previous setting. */
-int kai0_gemm_set_regstage(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Few-row weight-streaming GEMM for the denoise loop (B*action_horizon <= a few 64-row tiles):

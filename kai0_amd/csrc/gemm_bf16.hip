@@ -270,9 +270,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
-    static_assert(SCH == 0 || (SCH == 1 && PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4) || (SCH == 3 && PP && NS == 4) ||
-                  (SCH == 4 && !PP && NS == 3 && BKT == 64 && MT == 4 && NT == 4),
-                  "schedules: 0 plain / two-buffer ping-pong, 1 quadrant (256x256x64), 3 ring (256x256x32), 4 register-staged (128x128x64)");
+    static_assert(SCH == 0 || (SCH == 1 && PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4) || (SCH == 3 && PP && NS == 4), "schedules: 0 plain / two-buffer ping-pong, 1 quadrant (256x256x64), 3 ring (256x256x32)");
     static_assert(!(PP && NS == 4) || SCH == 3, "the ring runs with every DMA piece between the MFMA rows");
     static_assert(NS >= 2 && (!PP || NS == 2 || (NS == 4 && BKT == 32)), "stages");
     static_assert(BKT == 64 || BKT == 32, "K-tile depth");
@@ -756,75 +754,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             }
         }
         if (grp == 0) lds_barrier();  // re-align the two groups
-    } else if constexpr (SCH == 4) {
-        // Register-staged loop for grids of at most one 4-wave block per CU (the B = 1 inference GEMMs; round 5).  With ONE wave per
-        // SIMD nothing hides what a wave's own instructions cost at issue, and an LDS-DMA piece costs its wave 100-180 cycles next
-        // to fragment reads (60 between bare MFMAs): the 8 pieces of a 128 x 128 x 64 tile were ~1000 of the ~1500 cycles the
-        // 4-stage DMA loop spends per K-tile, its 32 MFMAs 512.  A plain 16-B buffer load into VGPRs issues in a few cycles and is
-        // asynchronous until its wait; the ds_write_b128 that puts it where the DMA would have (same lane-linear image, same
-        // source-side swizzle, same fragment reads) costs 13.  One wave per SIMD owns 512 registers, so THREE K-tiles (96 VGPRs)
-        // stay in flight in registers — the depth the 4-stage loop had — in front of a 3-slot LDS ring:
-        //   step(t): write tile t+1 (registers, loaded three steps ago) -> slot (t+1) % 3 | request tile t+4 into the freed
-        //            registers | fragments + 32 MFMAs of tile t out of slot t % 3 | barrier.
-        //   WAR: slot (t+1) % 3 was last read in step t-2, two barriers ago.  RAW: tile t+1's ds_writes are retired by the
-        //   lgkmcnt(0) in front of the barrier that ends step t.  Loads past the last tile are issued out of range (zero fill,
-        //   no memory traffic), so the number of loads in flight is the same in every step and hipcc's own counted vmcnt holds.
-        constexpr int NP = NA + NB;
-        u32x4 r0[NP], r1[NP], r2[NP];
-        auto gload = [&](u32x4 (&r)[NP], int kt) {
-#pragma unroll
-            for (int idx = 0; idx < NP; ++idx) {
-                const uint32_t off = p.ablate == 1 ? OOB : piece_off(kt, idx);
-                const bool second = B_KC && pair && idx >= NA && (((wave * NB + (idx - NA)) * KC_RPP) & 32);
-                r[idx] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(idx < NA ? a_rsrc : (second ? b2_rsrc : b_rsrc), (int)off, 0, 0));
-            }
-        };
-        auto lwrite = [&](const u32x4 (&r)[NP], int slot) {
-            char* sa = smem + slot * STAGE + wave * (NA * 1024) + lane * 16;
-            char* sb = smem + slot * STAGE + A_TILE + wave * (NB * 1024) + lane * 16;
-#pragma unroll
-            for (int idx = 0; idx < NP; ++idx)
-                *reinterpret_cast<u32x4*>(idx < NA ? sa + idx * 1024 : sb + (idx - NA) * 1024) = r[idx];
-        };
-        auto compute = [&](int slot) {
-            const char* ta = smem + slot * STAGE;
-            const char* tb = ta + A_TILE;
-#pragma unroll
-            for (int ks = 0; ks < BK / 32; ++ks) {
-                bf16x8 bfr[NT], af[MT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
-#pragma unroll
-                for (int t = 0; t < MT; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + t * 16, ks);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-        };
-        gload(r0, 0);
-        gload(r1, 1);
-        gload(r2, 2);
-        lwrite(r0, 0);
-        gload(r0, 3);
-        lds_barrier();
-        for (int kt = 0; kt < nk; kt += 3) {
-            lwrite(r1, 1);
-            gload(r1, kt + 4);
-            compute(0);
-            lds_barrier();
-            if (kt + 1 >= nk) break;
-            lwrite(r2, 2);
-            gload(r2, kt + 5);
-            compute(1);
-            lds_barrier();
-            if (kt + 2 >= nk) break;
-            lwrite(r0, 0);
-            gload(r0, kt + 6);
-            compute(2);
-            lds_barrier();
-        }
-        // (every step ends with a barrier behind an lgkmcnt(0): no ds_write is pending when the epilogue slabs reuse the ring)
     } else {
         // iteration kt: [tile kt landed (counted vmcnt) | barrier | issue tile kt+NS-1 into the slot tile kt-1 just left |
         // compute tile kt].  The barrier orders both the RAW on tile kt and the WAR on the slot being refilled.
@@ -1667,19 +1596,12 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
 
 int g_gemm_cfg = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
 int g_gemm_persist = [] { const char* e = getenv("KAI0_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-int g_gemm_regstage = [] { const char* e = getenv("KAI0_GEMM_REGSTAGE"); return e ? atoi(e) : 1; }();  // A/B of the round-5 B = 1 loop
 
 }  // namespace
 
 KAI0_API int kai0_gemm_set_cfg(int cfg) {
     const int old = g_gemm_cfg;
     g_gemm_cfg = cfg;
-    return old;
-}
-
-KAI0_API int kai0_gemm_set_regstage(int on) {
-    const int old = g_gemm_regstage;
-    g_gemm_regstage = on;
     return old;
 }
 
@@ -1865,7 +1787,6 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     else if (big && d->b_kc && forced != 5) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);  // NT: quadrant schedule
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
-    else if (deep && g_gemm_regstage) rc = launch_cfg<2, 2, 4, 4, false, 3, 64, 4>(d, p, batch, s);  // <= 1 block per CU: register-staged loop
     else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);
     else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);
     if (rc) return rc;

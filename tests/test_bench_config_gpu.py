@@ -12,8 +12,8 @@ vocab 2048; the launches that only exist at M = 30 976 were covered as isolated 
   (a') the fp32 oracle (full vocab, identical weights) on samples 0 and 17 of the batch: loss rows <= 1e-2 (BASELINE.md section 4);
   (b) two optimizer steps of that Trainer with prompt token ids drawn from the WHOLE vocabulary (ids far above 2048): the embedding
       rows a step touches against `torch.optim.AdamW(betas 0.9 / 0.95, eps 1e-8, wd 1e-10)` fed the same clipped gradients (f32
-      masters within 1e-6 absolute + 1e-5 relative, the bf16 rows within one ulp); rows never touched stay bit-identical with zero
-      moments; the engine's row-activity flags name exactly the touched rows.
+      masters within 2 f32 ulp, both moments within 1e-5 of torch's optimizer state, the bf16 rows within one ulp); rows never touched
+      stay bit-identical with zero moments; the engine's row-activity flags name exactly the rows of valid prompt tokens.
 Reference: pi0_pytorch.py:316-373, train_pytorch.py:547-567, optimizer.py:15-85.  Figures -> gpurun_out/parity_r05.txt (committed as
 profiles/parity_r05.txt)."""
 
@@ -252,10 +252,17 @@ def test_two_trainer_steps_at_full_vocab_match_torch_adamw_on_the_touched_rows(b
         master = mview(b.master)[touched]
         d_abs = float((master - ref_p.detach()).abs().max())
         upd = float((ref_p.detach() - w0[touched].float()).abs().max())
-        ok = torch.isclose(master, ref_p.detach(), rtol=1e-5, atol=1e-6)
+        # at the warm-up lr of the benchmarked schedule (2.5e-8 .. 5e-8) an update is a few f32 ulps of a 0.02-sized master value: the
+        # masters must agree to 2 ulp (rtol 2.4e-7), and what verifies the gradient path / clip coefficient / moment recursion to
+        # working precision are the moments themselves against torch's optimizer state
+        ok = torch.isclose(master, ref_p.detach(), rtol=2.4e-7, atol=0.0)
+        st_ref = ropt.state[ref_p]
+        m_ok = torch.isclose(mview(b.exp_avg)[touched], st_ref["exp_avg"], rtol=1e-5, atol=1e-12)
+        v_ok = torch.isclose(mview(b.exp_avg_sq)[touched], st_ref["exp_avg_sq"], rtol=1e-5, atol=1e-20)
+        assert bool(m_ok.all()) and bool(v_ok.all()), (float((~m_ok).float().mean()), float((~v_ok).float().mean()))
         ulp = (table.detach()[touched].view(torch.int16).int() - ref_p.detach().to(BF16).view(torch.int16).int()).abs()
         _report(f"(b) step {step + 1}: lr {lr:.3e}, |g| {float(norm):.4f}, clip {coef:.4f}; {touched.numel()} touched embedding rows ({int((touched >= 2048).sum())} with "
-                f"id >= 2048): f32 master vs torch.optim.AdamW max |d| {d_abs:.2e} (largest update {upd:.2e}), bf16 rows differing by one ulp "
+                f"id >= 2048): f32 master vs torch.optim.AdamW max |d| {d_abs:.2e} (<= 2 f32 ulp; largest update {upd:.2e}), first / second moments equal torch's state to 1e-5, bf16 rows differing by one ulp "
                 f"{float((ulp == 1).float().mean()):.2e}, by more {int((ulp > 1).sum())}")  # fmt: skip
         assert bool(ok.all()) and int((ulp > 1).sum()) == 0 and float((ulp == 1).float().mean()) < 1e-3
     # rows no step touched: bit-identical weights, zero moments, flagged idle
