@@ -30,6 +30,12 @@
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
+// timing ablations (phases switched off; results wrong) exist only in builds made with KAI0_HIPCC_FLAGS=-DKAI0_ABLATE
+#ifdef KAI0_ABLATE
+#define KAI0_ABL(p) ((p).ablate)
+#else
+#define KAI0_ABL(p) 0
+#endif
 constexpr int KC_LDS_MAX = 2048;  // key codes staged in LDS per block (8 KiB): covers S = 1018 and the estimator's 1786
 
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, char* lds_dst_wave_uniform) {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
                     pb[mt][nt][r] = f2bf(e);
                 }
         // P tile -> global through a wave-private LDS transposition: write [16 QT q][64 keys] rows, read 16 B per lane
-        if (p.P != nullptr && !(p.ablate & 1)) {
+        if (p.P != nullptr && !(KAI0_ABL(p) & 1)) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
     // group g contributing keys {4g..4g+3} of each — the same 8 keys on both operands.  Batched like the logits: the transpose
     // reads of four output d-tiles (8 ds_read_b64_tr_b16) run one batch ahead of the MFMAs that consume them.
     auto pv_tile = [&](const char* tv, const bf16x4 (&pb)[4][QT]) {
-        if (p.ablate & 4) return;
+        if (KAI0_ABL(p) & 4) return;
         constexpr int NB = OMT / 4;              // batches per 32-key step
         bf16x8 vf[2][4];
         auto rdv = [&](int b, bf16x8 (&dst)[4]) {
@@ -433,12 +439,12 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         for (int it = 0; it < nlive; ++it) {
             const int kt = tile_at(it);
             const int buf = NST == 2 ? (it & 1) : 0;
-            if (NST == 2 && it + 1 < nlive && !(p.ablate & 8)) stage(tile_at(it + 1), buf ^ 1, true);
+            if (NST == 2 && it + 1 < nlive && !(KAI0_ABL(p) & 8)) stage(tile_at(it + 1), buf ^ 1, true);
             const char* tk = smem + buf * STAGE;
             int kc[4][4];
             load_kcodes(kt, kc);
             f32x4 s[4][QT];
-            if (p.ablate & 16) {
+            if (KAI0_ABL(p) & 16) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = (p.ablate & 32) ? s[mt][nt][r] : live ? __expf(s[mt][nt][r] - mn) : 0.f;    // masked: exp(-inf) = 0
+                        const float e = (KAI0_ABL(p) & 32) ? s[mt][nt][r] : live ? __expf(s[mt][nt][r] - mn) : 0.f;    // masked: exp(-inf) = 0
                         lsum += e;
                         pb[mt][nt][r] = f2bf(e);
                     }
@@ -503,9 +509,9 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
     stage(0, 0, false);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    for (int kt = 0; kt < ((p.ablate & 2) ? 0 : ntiles); ++kt) {
+    for (int kt = 0; kt < ((KAI0_ABL(p) & 2) ? 0 : ntiles); ++kt) {
         const int buf = NST == 2 ? (kt & 1) : 0;
-        if (NST == 2 && kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, false);
+        if (NST == 2 && kt + 1 < ntiles && !(KAI0_ABL(p) & 8)) stage(kt + 1, buf ^ 1, false);
         int kc[4][4];
         load_kcodes(kt, kc);
         f32x4 s[4][QT];
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         }
         if (NST == 1) {  // one buffer: every wave is done reading tile kt before tile kt + 1 overwrites it
             lds_barrier();
-            if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, 0, false);
+            if (kt + 1 < ntiles && !(KAI0_ABL(p) & 8)) stage(kt + 1, 0, false);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
@@ -560,12 +566,12 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
     lds_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = NST == 2 ? (kt & 1) : 0;
-        if (NST == 2 && kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, buf ^ 1, true);
+        if (NST == 2 && kt + 1 < ntiles && !(KAI0_ABL(p) & 8)) stage(kt + 1, buf ^ 1, true);
         const char* tk = smem + buf * STAGE;
         int kc[4][4];
         load_kcodes(kt, kc);
         f32x4 s[4][QT];
-        if (p.ablate & 16) {
+        if (KAI0_ABL(p) & 16) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -576,11 +582,11 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
         emit_tile(kt, tk + K_BYTES, s, m_run, inv_l);
         if (NST == 1) {
             lds_barrier();
-            if (kt + 1 < ntiles && !(p.ablate & 8)) stage(kt + 1, 0, true);
+            if (kt + 1 < ntiles && !(KAI0_ABL(p) & 8)) stage(kt + 1, 0, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the P stores are older than these pieces)
         } else {
         // the DMA of tile kt+1 (issued at the top of this iteration) must have landed; the P stores issued after it may fly
-        if (p.P != nullptr && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
+        if (p.P != nullptr && !(KAI0_ABL(p) & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         lds_barrier();
@@ -637,8 +643,12 @@ KAI0_API int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream) {
     p.scale = d->scale;
     p.lse = d->lse; p.s_lse = d->s_lse;
     KAI0_REQUIRE(d->lse == nullptr || d->s_lse >= d->rows, "kai0_attn_fwd: s_lse=%lld < rows", (long long)d->s_lse);
+#ifdef KAI0_ABLATE
     static const int ablate = [] { const char* e = getenv("KAI0_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
+#else
+    p.ablate = 0;
+#endif
     p.nt_p = 1;
     const int kc_keys = ((d->Sk + 63) / 64) * 64;
     p.kc_lds_keys = kc_keys <= KC_LDS_MAX ? kc_keys : 0;  // longer key ranges read their codes from global

@@ -29,6 +29,14 @@ namespace {
 
 constexpr int BK = 64;
 
+// timing ablations (no DMA inside the K loop: the compute + LDS-read ceiling) exist only in builds made with
+// KAI0_HIPCC_FLAGS=-DKAI0_ABLATE (tools/gemm_ablate.py); the shipped kernels carry no ablation branch
+#ifdef KAI0_ABLATE
+#define KAI0_ABL(p) ((p).ablate)
+#else
+#define KAI0_ABL(p) 0
+#endif
+
 struct RowMap {
     int32_t rpb;
     int64_t bs, off;
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             uint32_t poff[NP];
             if constexpr (SCH == 0) {
 #pragma unroll
-                for (int pi = 0; pi < NP; ++pi) poff[pi] = p.ablate == 1 ? OOB : piece_off(u + 3, pi);
+                for (int pi = 0; pi < NP; ++pi) poff[pi] = KAI0_ABL(p) == 1 ? OOB : piece_off(u + 3, pi);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SCH == 0) {
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 }
                 if (SCH == 3 && (i & 1) == 0) {  // (the offset arithmetic sits in the MFMA shadow too)
                     __builtin_amdgcn_sched_barrier(0);
-                    poff[i >> 1] = p.ablate == 1 ? OOB : piece_off(u + 3, i >> 1);
+                    poff[i >> 1] = KAI0_ABL(p) == 1 ? OOB : piece_off(u + 3, i >> 1);
                     piece_issue(poff[i >> 1], pslot, i >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -616,7 +624,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                     const int kr = k0 + (isb ? hb_kr[x] : ha_kr[x]);
                     if (kr < kend && o != OOB) off = o + (uint32_t)(isb ? p.bmap(kr) : p.amap(kr)) * (isb ? ldb2 : lda2);
                 }
-                if (p.ablate == 1) off = OOB;
+                if (KAI0_ABL(p) == 1) off = OOB;
                 glds16(isb ? ((pair && h == 1) ? b2_rsrc : b_rsrc) : a_rsrc, off, base + (isb ? hb_lds[x] : ha_lds[x]));
             }
         };
@@ -734,7 +742,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             const char* tb = ta + A_TILE;
 #pragma unroll
             for (int ks = 0; ks < BK / 32; ++ks) {
-                if (ks == 0 && kt + 1 < nk && p.ablate != 1) stage(kt + 1, buf ^ 1);
+                if (ks == 0 && kt + 1 < nk && KAI0_ABL(p) != 1) stage(kt + 1, buf ^ 1);
                 bf16x8 bfr[NT], af[MT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             lds_barrier();
-            if (kt + NS - 1 < nk && p.ablate != 1) stage(kt + NS - 1, slot_p);
+            if (kt + NS - 1 < nk && KAI0_ABL(p) != 1) stage(kt + NS - 1, slot_p);
             const char* ta = smem + slot_c * STAGE;
             const char* tb = ta + A_TILE;
     #pragma unroll
@@ -1594,7 +1602,7 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     return 0;
 }
 
-int g_gemm_cfg = [] { const char* e = getenv("KAI0_GEMM_CFG"); return e ? atoi(e) : 0; }();
+int g_gemm_cfg = 0;  // kai0_gemm_set_cfg (tools / tests): no environment switch
 int g_gemm_persist = [] { const char* e = getenv("KAI0_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
 
 }  // namespace
@@ -1699,13 +1707,16 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.gate = (const bf16_t*)d->gate; p.gate_rpb = d->gate_rpb; p.gate_ld = d->gate_ld;
     p.accumulate = d->accumulate;
     p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.sR1 = d->sR1; p.sR2 = d->sR2;
+#ifdef KAI0_ABLATE
     static const int ablate = [] { const char* e = getenv("KAI0_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     p.ablate = ablate;
-    // non-temporal stores for what only the backward / the optimizer reads again (KAI0_GEMM_NT=0: plain stores, for A/B runs)
-    // (bit 0: pre-activation outputs, bit 1: C when the caller sets c_nontemporal)
-    static const int nt_on = [] { const char* e = getenv("KAI0_GEMM_NT"); return e ? atoi(e) : 3; }();
-    p.nt_pre = nt_on & 1;
-    p.nt_c = (nt_on & 2) && d->c_nontemporal;  // diagnostics: 1 = no DMA in the K loop (compute + LDS-read ceiling)
+#else
+    p.ablate = 0;
+#endif
+    // non-temporal stores for what only the backward / the optimizer reads again: the pre-activation outputs always, C when the
+    // caller sets c_nontemporal (weight gradients)
+    p.nt_pre = 1;
+    p.nt_c = d->c_nontemporal != 0;
     p.rowvec = d->rowvec; p.rv_s1 = d->rv_s1; p.rv_s2 = d->rv_s2; p.rv_ld = d->rv_ld;
     p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {

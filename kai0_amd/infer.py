@@ -12,7 +12,7 @@ MI355X-first choices:
     read once instead of once per step) — and, being a function of the weights and the schedule only (no request input
     enters: sincos(t) -> time MLP -> `dense`), ONCE PER ENGINE, not per request: the engine is dropped whenever a weight
     changes (`_fingerprint`), so the table is constant for its lifetime, like the RoPE inverse frequencies
-    (KAI0_INFER_CACHE_MODS=0 recomputes it inside every call);
+    (round 5: the switch that recomputed it inside every call is gone — one way to do it);
   * the last prefix layer stops after its K/V projection — nothing reads its attention/MLP output;
   * the whole call (SigLIP -> prefix -> all denoise steps) is recorded once into a hipGraph
     (torch.cuda.CUDAGraph on ROCm is hipGraph) and replayed per request: no per-op Python or launch cost.
@@ -54,6 +54,11 @@ def euler_times(num_steps: int) -> list[float]:
 
 
 class InferenceEngine:
+    # test hooks (class attributes, read when an engine is built — not environment switches): the generic per-layer denoise path at
+    # shapes the production stack would take, and the norms behind split-K Linears as launches of their own
+    force_generic = False
+    fuse_split_norm = True
+
     def __init__(self, model, batch: int, n_lang: int, n_cam: int):
         self.model = model
         pe = model.paligemma_with_expert
@@ -78,24 +83,23 @@ class InferenceEngine:
         self.q_buf = torch.zeros((B, S_ld, H * HD), dtype=BF16, device=dev)
         self.att_buf = torch.zeros((B, S_ld, H * HD), dtype=BF16, device=dev)
         self.use_graph = os.environ.get("KAI0_INFER_GRAPH", "1") != "0"
-        # few denoise rows (B * horizon <= 128): weight-streaming GEMMs with fused RoPE / GeGLU / gated-residual epilogues
+        # The production denoise stack (`fast`): weight-streaming in-block kernels with fused RoPE / GeGLU / gated-residual epilogues,
+        # adaRMS folded into per-step weights, one-launch step seams, the two-launch decode attention — for the shapes it was built for
+        # (few denoise rows, the pi0.5 widths, <= 1024 keys).  Anything else (the tiny test models, other widths) runs the generic
+        # per-layer path `_denoise_step` over the plain GEMM.  Round 5: the two superseded stacks (split-K partials + combine launches;
+        # adaRMS as a projection prologue) and their switches are gone.
         ecfg = pe.exp_cfg
-        self.skinny = (B * self.Hs <= 128 and os.environ.get("KAI0_INFER_SKINNY", "1") != "0"
-                       and all(k % 512 == 0 for k in (ecfg.width, ecfg.mlp_dim, H * HD)) and HD % 32 == 0
-                       and ecfg.width % 32 == 0 and ecfg.mlp_dim % 16 == 0)  # fmt: skip
+        self.F = ecfg.mlp_dim
+        self.fast = (not self.force_generic and B * self.Hs <= 128 and ecfg.width == 1024 and NQ_ok(H * HD) and self.F in (1024, 2048, 4096) and HD == 256
+                     and self.S <= 1024 and self.P % 8 == 0)  # fmt: skip
         self._weights_tag = self._fingerprint()
-        if self.skinny:
-            self._build_skinny()
+        if self.fast:
+            self._build_fast()
         self._build_stacked()
         self._times_dev = {}
-        self.glue = os.environ.get("KAI0_INFER_GLUE", "1") != "0"
-        # the norm behind a split-K Linear of the SigLIP / prefix passes inside that Linear's reduction launch
-        self.fuse_norm = os.environ.get("KAI0_INFER_FUSE_NORM", "1") != "0"
+        # the norm behind a split-K Linear of the SigLIP / prefix passes runs inside that Linear's reduction launch
+        self.fuse_norm = bool(self.fuse_split_norm)
         self._mods_cache = {}
-        self.cache_mods = os.environ.get("KAI0_INFER_CACHE_MODS", "1") != "0"
-        # adaRMS folded into the expert's q|k|v and gate|up weights per Euler step (_fold_modulations; KAI0_INFER_FOLD=0: the adaRMS
-        # prologue inside the projection kernels, round 3's form, for A/B runs)
-        self.fold = self.cache_mods and os.environ.get("KAI0_INFER_FOLD", "1") != "0"
         self._fold_cache = {}
         self._graph = None
         self._graph_steps = None
@@ -261,42 +265,23 @@ class InferenceEngine:
         att = torch.zeros((B, P), dtype=torch.bool, device=pad.device)
         return embs.view(B, P, D), pad, att
 
-    def _build_skinny(self):
+    def _build_fast(self):
         ex = self.pe.gemma_expert.model
-        B, Hs, H, HD, De, dev = self.B, self.Hs, self.H, self.HD, self.De, self.dev
-        M = B * Hs
-        self.F = ex.layers[0].mlp.gate_proj.weight.shape[0]
-        # stacked copies (0.5 GB): q|k|v and gate|up become one weight stream and one launch each
-        self.w_qkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
-                      for l in ex.layers]  # fmt: skip
-        self.w_gu = [torch.cat([l.mlp.gate_proj.weight, l.mlp.up_proj.weight], 0).contiguous() for l in ex.layers]
-        # in-block kernels stream the weights as fragment-major 1-KiB blocks (ops.pack_skinny_weight): every wave-instruction of
-        # the stream is one contiguous KiB instead of sixteen 64-B pieces of sixteen rows
-        self.packed = os.environ.get("KAI0_SK2_PACKED", "1") != "0"
-        self.w_o = [l.self_attn.o_proj.weight for l in ex.layers]
-        self.w_d = [l.mlp.down_proj.weight for l in ex.layers]
-        # o_proj / down_proj: split-K partial products, finished by adarms_combine
-        self.S_o, self.S_d = ops.skinny_split_k(De, H * HD), ops.skinny_split_k(De, self.F)
-        self.ws_o = ops.skinny_workspace(M, De, self.S_o, dev)
-        self.ws_d = ops.skinny_workspace(M, De, self.S_d, dev)
-        # (superseded for K in {1024, 2048, 4096}: the in-block kernels below need neither partial products nor a combine launch)
-        self.inblock = (os.environ.get("KAI0_INFER_INBLOCK", "1") != "0" and De == 1024 and NQ_ok(H * HD) and self.F in (1024, 2048, 4096)
-                        and De % 128 == 0)  # fmt: skip
-        self.packed = self.packed and self.inblock and HD == 256 and self.S <= 1024 and self.P % 8 == 0  # (= the in-block stack runs)
-        self.w_qkv_raw, self.w_gu_raw = self.w_qkv, self.w_gu  # row-major stacked copies (the folded per-step weights are cut from them)
-        if self.packed:
-            self.w_qkv = [ops.pack_skinny_weight(w) for w in self.w_qkv]
-            self.w_gu = [ops.pack_skinny_weight(w) for w in self.w_gu]
-            self.w_o = [ops.pack_skinny_weight(w) for w in self.w_o]
-            self.w_d = [ops.pack_skinny_weight(w) for w in self.w_d]
+        B, HD, dev = self.B, self.HD, self.dev
+        # stacked copies (0.5 GB): q|k|v and gate|up become one weight stream and one launch each; the in-block kernels stream the
+        # weights as fragment-major 1-KiB blocks (ops.pack_skinny_weight): every wave-instruction of the stream is one contiguous KiB
+        # instead of sixteen 64-B pieces of sixteen rows.  The row-major stacked copies are what the folded per-step weights are cut from.
+        self.w_qkv_raw = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
+                          for l in ex.layers]  # fmt: skip
+        self.w_gu_raw = [torch.cat([l.mlp.gate_proj.weight, l.mlp.up_proj.weight], 0).contiguous() for l in ex.layers]
+        self.w_o = [ops.pack_skinny_weight(l.self_attn.o_proj.weight) for l in ex.layers]
+        self.w_d = [ops.pack_skinny_weight(l.mlp.down_proj.weight) for l in ex.layers]
         # all 37 adaRMS `dense` layers stacked: the modulations of every layer and step come out of ONE f32 GEMM
         dens = [m for l in ex.layers for m in (l.input_layernorm.dense, l.post_attention_layernorm.dense)] + [ex.norm.dense]
         self.w_mod = torch.cat([m.weight for m in dens], 0).contiguous()
         self.b_mod = torch.cat([m.bias for m in dens], 0).contiguous()
-        # one-launch decode attention: needs the value cache transposed ([HD][keys])
-        self.decode_attn = HD == 256 and self.S <= 1024 and self.P % 8 == 0
-        if self.decode_attn:
-            self.vt_all = torch.zeros((self.L, B, HD, self.S_ld), dtype=BF16, device=dev)
+        # decode attention: needs the value cache transposed ([HD][keys])
+        self.vt_all = torch.zeros((self.L, B, HD, self.S_ld), dtype=BF16, device=dev)
 
     # ---------------------------------------------------------------------------------------------- attention
     def _attend(self, l: int, q0: int, Sq: int, Sk: int, qcode, kcode):
@@ -409,7 +394,7 @@ class InferenceEngine:
         _lib.call("kai0_time_sincos", tt.data_ptr(), te.data_ptr(), n * B, De, 4e-3, 4.0, ops._stream())
         x = ops.silu_f32(ops.linear_f32(te, model.time_mlp_in.weight, model.time_mlp_in.bias))
         cond = ops.silu_f32(ops.linear_f32(x, model.time_mlp_out.weight, model.time_mlp_out.bias))
-        if not self.skinny:
+        if not self.fast:
             ex = self.pe.gemma_expert.model
             mods = [(ops.linear_f32(cond, l.input_layernorm.dense.weight, l.input_layernorm.dense.bias),
                      ops.linear_f32(cond, l.post_attention_layernorm.dense.weight, l.post_attention_layernorm.dense.bias))
@@ -439,7 +424,9 @@ class InferenceEngine:
                     scale, shift = m[r, :De], m[r, De : 2 * De]
                     wf = w.float()
                     wp = (wf * (1.0 + scale)[None, :]).to(BF16)
-                    ent.append((ops.pack_skinny_weight(wp) if self.packed else wp.contiguous(), (wf @ shift).contiguous()))
+                    # c = W shift through the library's own exact-f32 GEMM (kai0_gemm_f32), not torch's matmul (rocBLAS gemv)
+                    cvec = ops.linear_f32(shift.reshape(1, De).contiguous(), wf).reshape(-1)
+                    ent.append((ops.pack_skinny_weight(wp), cvec.contiguous()))
                 per_layer.append(ent)
             out.append(per_layer)
         return out
@@ -451,8 +438,10 @@ class InferenceEngine:
         return self._gates[rows, c0 : c0 + De]
 
     def _expert_stack_folded(self, xs, sq, step: int, rows, folded):
-        """_expert_stack_inblock with the adaRMS norms folded into the weights: the projections read the raw residual stream, the
-        producers (denoise glue, o_proj, down_proj) hand the rows' partial sums of squares along (`sq`: [64, M] f32, `parts` valid)."""
+        """All expert layers of one denoise step, 6 launches per layer and no partial products: [q|k|v + RoPE], logits, softmax + P V,
+        [o_proj + gated residual], [gate|up + GeGLU], [down_proj + gated residual], with the adaRMS norms folded into the weights: the
+        projections read the raw residual stream, the producers (denoise glue, o_proj, down_proj) hand the rows' partial sums of
+        squares along (`sq`: [64, M] f32, `parts` valid); the gates are precomputed for all steps (`_gate`)."""
         B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
         M, dev = B * Hs, self.dev
         cos, sin = self._rope_cs
@@ -466,7 +455,7 @@ class InferenceEngine:
                             segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
                                   (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
                             c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, eps=layer.input_layernorm.eps,
-                            w_packed=self.packed, rowsq_in=sq, rowsq_parts=parts, cvec=cq)  # fmt: skip
+                            w_packed=True, rowsq_in=sq, rowsq_parts=parts, cvec=cq)  # fmt: skip
             ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
                             rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
                             vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
@@ -474,90 +463,22 @@ class InferenceEngine:
             sq1 = torch.empty((De // 16, M), dtype=F32, device=dev)
             ops.skinny_gemm(self.att_buf, self.w_o[l], M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
                             a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
-                            residual=xs, ldr=De, w_packed=self.packed, rowsq_out=sq1)  # fmt: skip
+                            residual=xs, ldr=De, w_packed=True, rowsq_out=sq1)  # fmt: skip
             h = torch.empty((M, F), dtype=BF16, device=dev)
             ops.skinny_gemm(x1, wg, M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
-                            segs=[(h, F, 0, F, 0)], eps=layer.post_attention_layernorm.eps, w_packed=self.packed,
+                            segs=[(h, F, 0, F, 0)], eps=layer.post_attention_layernorm.eps, w_packed=True,
                             rowsq_in=sq1, rowsq_parts=De // 16, cvec=cg)  # fmt: skip
             xs = torch.empty((M, De), dtype=BF16, device=dev)
             sq = torch.empty((De // 16, M), dtype=F32, device=dev)
             ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
-                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=self.packed,
+                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=True,
                             rowsq_out=sq)  # fmt: skip
             parts = De // 16
         return xs  # the step seam (kai0_denoise_glue) applies the final norm
 
-    def _expert_stack_inblock(self, xs, mods, mf, rows, final_norm: bool = True):
-        """All expert layers of one denoise step, 6 launches per layer and no partial products: [adaRMS -> q|k|v + RoPE],
-        logits, softmax + P V, [o_proj + gated residual], [adaRMS -> gate|up + GeGLU], [down_proj + gated residual].  The norms
-        run as prologues of the projections that consume them; the gates are precomputed for all steps (`_gate`)."""
-        B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
-        M, dev = B * Hs, self.dev
-        cos, sin = self._rope_cs
-        layers = self.pe.gemma_expert.model.layers
-        NQ = H * HD
-        ld = self._mod_ld
-        for l, layer in enumerate(layers):
-            ops.skinny_gemm(xs, self.w_qkv[l], M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2, split_k=-1,
-                            segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
-                                  (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
-                            c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, mod=mods[l][0][rows], mod_ld=ld,
-                            mod_rpb=Hs, eps=layer.input_layernorm.eps, w_packed=self.packed)  # fmt: skip
-            ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
-                            rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
-                            vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
-            x1 = torch.empty((M, De), dtype=BF16, device=dev)
-            ops.skinny_gemm(self.att_buf, self.w_o[l], M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
-                            a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
-                            residual=xs, ldr=De, w_packed=self.packed)  # fmt: skip
-            h = torch.empty((M, F), dtype=BF16, device=dev)
-            ops.skinny_gemm(x1, self.w_gu[l], M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
-                            segs=[(h, F, 0, F, 0)], mod=mods[l][1][rows], mod_ld=ld, mod_rpb=Hs,
-                            eps=layer.post_attention_layernorm.eps, w_packed=self.packed)  # fmt: skip
-            xs = torch.empty((M, De), dtype=BF16, device=dev)
-            ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
-                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=self.packed)  # fmt: skip
-        if not final_norm:
-            return xs  # the step seam (kai0_denoise_glue) applies the final norm
-        out, _ = ops.adarms(xs, mf[rows].contiguous(), Hs, self.pe.gemma_expert.model.norm.eps)
-        return out
-
-    def _expert_stack_skinny(self, xs, mods, mf, rows):
-        """All expert layers of one denoise step, 8 launches per layer: q|k|v+RoPE, logits, softmax, P V (+reduce),
-        o_proj partials, [sum + gated residual + adaRMS], gate|up+GeGLU, down_proj partials, [sum + gated residual +
-        the NEXT layer's (or the final) adaRMS]."""
-        B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
-        M, dev = B * Hs, self.dev
-        cos, sin = self._rope_cs
-        layers = self.pe.gemma_expert.model.layers
-        NQ = H * HD
-        cm = lambda t: t[rows].contiguous()  # noqa: E731 - the stacked modulations are strided views
-        hs, gate1 = ops.adarms(xs, cm(mods[0][0]), Hs, layers[0].input_layernorm.eps)
-        for l, layer in enumerate(layers):
-            ops.skinny_gemm(hs, self.w_qkv[l], M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2,
-                            segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
-                                  (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2) if self.decode_attn
-                                  else (self.v_cache[l], HD, NQ + HD, NQ + 2 * HD, 0)],
-                            c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2)  # fmt: skip
-            if self.decode_attn:
-                ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
-                                rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
-                                vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
-            else:
-                self._attend(l, P, Hs, P + Hs, self.qcode, self.kcode)
-            ops.skinny_gemm(self.att_buf, layer.self_attn.o_proj.weight, M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=self.S_o,
-                            workspace=self.ws_o, a_map=(Hs, S_ld, P))  # fmt: skip
-            x1, hs, gate2 = ops.adarms_combine(self.ws_o, gate1, xs, cm(mods[l][1]), Hs, layer.post_attention_layernorm.eps)
-            h = torch.empty((M, F), dtype=BF16, device=dev)
-            ops.skinny_gemm(hs, self.w_gu[l], M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, segs=[(h, F, 0, F, 0)])
-            ops.skinny_gemm(h, layer.mlp.down_proj.weight, M=M, N=De, K=F, lda=F, ldw=F, split_k=self.S_d, workspace=self.ws_d)
-            last = l + 1 == len(layers)
-            nmod = cm(mf) if last else cm(mods[l + 1][0])
-            neps = self.pe.gemma_expert.model.norm.eps if last else layers[l + 1].input_layernorm.eps
-            xs, hs, gate1 = ops.adarms_combine(self.ws_d, gate2, x1, nmod, Hs, neps)
-        return hs  # = final adaRMS norm of the last residual stream
-
     def _denoise_step(self, x_t, step: int, mods, mf):
+        """One Euler step on the generic path (shapes the production stack was not built for): per layer adaRMS, three projection
+        GEMMs into the static buffers, RoPE, attention, o_proj + gated residual, adaRMS, GeGLU MLP + gated residual."""
         model, pe = self.model, self.pe
         B, P, Hs, De = self.B, self.P, self.Hs, self.De
         H, HD, S_ld = self.H, self.HD, self.S_ld
@@ -566,11 +487,6 @@ class InferenceEngine:
         a = ops.linear_f32(x_t.view(B * Hs, self.A), model.action_in_proj.weight, model.action_in_proj.bias)
         xs = ops.cast(a, BF16)
         rows = slice(step * B, (step + 1) * B)
-        if self.skinny:
-            stack = self._expert_stack_inblock if (self.inblock and self.decode_attn) else self._expert_stack_skinny
-            out = stack(xs, mods, mf, rows)
-            v = ops.linear_f32(ops.cast(out, F32), model.action_out_proj.weight, model.action_out_proj.bias)
-            return v.view(B, Hs, self.A)
         for l, layer in enumerate(ex.layers):
             m1, m2 = mods[l][0][rows], mods[l][1][rows]
             hs, gate1 = ops.adarms(xs, m1, Hs, layer.input_layernorm.eps)
@@ -597,27 +513,22 @@ class InferenceEngine:
         if tuple(times) not in self._times_dev:  # H2D copy: must happen outside graph capture (warm-up run)
             self._times_dev[tuple(times)] = torch.tensor(times, dtype=F32).repeat_interleave(self.B).to(self.dev)
         self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
-        if self.cache_mods:
-            hit = self._mods_cache.get(tuple(times))
-            if hit is None:  # first (warm-up) run of this schedule: computed eagerly, kept for the engine's lifetime
-                mods, mf = self._modulations(times)
-                hit = self._mods_cache[tuple(times)] = (mods, mf, self._mod_ld if self.skinny else None, self._gates if self.skinny else None)
-                if self.skinny and self.inblock and self.decode_attn and self.glue and self.fold:
-                    self._fold_cache[tuple(times)] = self._fold_modulations(mods, len(times))
-            mods, mf = hit[0], hit[1]
-            if self.skinny:
-                self._mod_ld, self._gates = hit[2], hit[3]
-        else:
+        hit = self._mods_cache.get(tuple(times))
+        if hit is None:  # first (warm-up) run of this schedule: computed eagerly, kept for the engine's lifetime
             mods, mf = self._modulations(times)
-        if self.skinny:
-            self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
-            if self.decode_attn:  # prefix value rows of every layer -> transposed cache, one launch
-                ops.transpose_strided(self.v_all, self.vt_all, R=self.P, C=self.HD, src_ld=self.HD, dst_ld=self.S_ld,
-                                      batch=self.L * self.B, src_bs=self.S_ld * self.HD, dst_bs=self.HD * self.S_ld)
+            hit = self._mods_cache[tuple(times)] = (mods, mf, self._mod_ld if self.fast else None, self._gates if self.fast else None)
+            if self.fast:
+                self._fold_cache[tuple(times)] = self._fold_modulations(mods, len(times))
+        mods, mf = hit[0], hit[1]
         x_t = noise.clone().contiguous()
-        if self.skinny and self.inblock and self.decode_attn and self.glue:
+        if self.fast:
+            self._mod_ld, self._gates = hit[2], hit[3]
+            self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
+            # prefix value rows of every layer -> transposed cache, one launch
+            ops.transpose_strided(self.v_all, self.vt_all, R=self.P, C=self.HD, src_ld=self.HD, dst_ld=self.S_ld,
+                                  batch=self.L * self.B, src_bs=self.S_ld * self.HD, dst_bs=self.HD * self.S_ld)
             # step seams in one launch each (kai0_denoise_glue): [final adaRMS -> action_out_proj -> Euler update] of step s and
-            # [action_in_proj -> bf16] of step s + 1 — six launches on the path below
+            # [action_in_proj -> bf16 + the rows' sums of squares] of step s + 1
             model, B, Hs, De = self.model, self.B, self.Hs, self.De
             M, n = B * Hs, len(times)
             x2 = x_t.view(M, self.A)
@@ -625,17 +536,14 @@ class InferenceEngine:
             wout, bout = model.action_out_proj.weight, model.action_out_proj.bias
             eps = self.pe.gemma_expert.model.norm.eps
             xs = torch.empty((M, De), dtype=BF16, device=self.dev)
-            folded = self._fold_cache.get(tuple(times)) if self.fold else None
-            sq = torch.empty((1, M), dtype=F32, device=self.dev) if folded is not None else None
+            folded = self._fold_cache[tuple(times)]
+            sq = torch.empty((1, M), dtype=F32, device=self.dev)
             ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs, rowsq_next=sq)
             for step in range(n):
                 rows = slice(step * B, (step + 1) * B)
-                if folded is not None:
-                    last = self._expert_stack_folded(xs, sq, step, rows, folded)
-                else:
-                    last = self._expert_stack_inblock(xs, mods, mf, rows, final_norm=False)
+                last = self._expert_stack_folded(xs, sq, step, rows, folded)
                 xs = torch.empty((M, De), dtype=BF16, device=self.dev) if step + 1 < n else None
-                sq = torch.empty((1, M), dtype=F32, device=self.dev) if (folded is not None and xs is not None) else None
+                sq = torch.empty((1, M), dtype=F32, device=self.dev) if xs is not None else None
                 ops.denoise_glue(x2, xs=last, mod=mf[rows], mod_ld=self._mod_ld, rows_per_batch=Hs, eps=eps, w_out=wout, b_out=bout,
                                  dt=dt, w_in=win if xs is not None else None, b_in=bin_ if xs is not None else None, xs_next=xs,
                                  rowsq_next=sq)

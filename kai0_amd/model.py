@@ -265,7 +265,7 @@ def build_mask_codes(pad_masks: torch.Tensor, att_masks: torch.Tensor):
 
 
 _EXPERT_STREAM = os.environ.get("KAI0_EXPERT_STREAM", "1") != "0"  # the action expert's chain on a second HIP stream
-_SKIP_DEAD_PREFIX = os.environ.get("KAI0_SKIP_DEAD_PREFIX", "1") != "0"  # last layer: no prefix o_proj / MLP (dead values)
+_SKIP_DEAD_PREFIX = True  # last layer: no prefix o_proj / MLP (dead values); set_skip_dead_prefix(False) computes them (tests)
 
 
 def set_expert_stream(on: bool) -> bool:

@@ -428,7 +428,7 @@ def _note_side_gradient(param) -> None:
 # the optimizer, so those sums are queued and run 32 per launch (kai0_reduce_partials_batch): flushed by join_streams (which
 # precedes every collective and the optimizer) and by a callback at the end of the backward pass.  Gradients handed back to
 # autograd as tensors are NOT deferred: AccumulateGrad may read them as soon as the node returns.
-_DEFER_REDUCE = os.environ.get("KAI0_DEFER_REDUCE", "1") != "0"
+_DEFER_REDUCE = True  # (round 5: the environment switch that launched every final sum on its own is gone)
 _DEFERRED: dict = {}  # device index -> [(ReduceItem fields, tensors kept alive, producing stream)]
 
 
@@ -575,7 +575,7 @@ def _as_fused(ts, widths):
     return t0.as_strided((t0.shape[0], total), (total, 1), t0.storage_offset())
 
 
-_FUSE_MULTI = os.environ.get("KAI0_FUSE_QKV", "1") != "0"
+_FUSE_MULTI = True  # q|k|v as one stacked GEMM whenever the widths allow it (round 5: no environment switch)
 
 
 class LinearMultiFn(torch.autograd.Function):
@@ -908,7 +908,7 @@ def geglu(g, u):
     return GegluFn.apply(g, u)
 
 
-_GEGLU_PAIR = os.environ.get("KAI0_GEGLU_PAIR", "1") != "0"  # 0: gate GEMM + up GEMM with the act-2 epilogue (A/B, tests)
+_GEGLU_PAIR = True  # set_geglu_pair(False): gate GEMM + up GEMM with the act-2 epilogue (tests; the fallback of widths % 32 != 0)
 
 
 def set_geglu_pair(on: bool) -> bool:
@@ -1476,8 +1476,8 @@ def joint_attention(pos, qcode, kcode, inv_freq, H, HD, seg_lens, qkv):
     return JointAttentionFn.apply(pos, qcode, kcode, inv_freq, H, HD, tuple(seg_lens), *qkv)
 
 
-_SIGLIP_BWD_FUSED = os.environ.get("KAI0_SIGLIP_BWD", "fused") != "gemm"
-_SIGLIP_FWD_DEDICATED = os.environ.get("KAI0_SIGLIP_FWD", "dedicated") != "general"  # (general: kai0_attn_fwd, A/B)
+_SIGLIP_BWD_FUSED = True  # (other shapes than 256 x 72 take the GEMM-based backward / the general forward kernel by shape)
+_SIGLIP_FWD_DEDICATED = True
 
 
 def siglip_attn_fwd(q, k, v, out, *, n_img, S, NH, HD, ld_qkv, ld_out, lse=None):

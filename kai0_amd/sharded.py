@@ -615,15 +615,11 @@ class ShardedDataParallel:
         # Every gradient producer overwrites its parameter's whole slice, so the 7 GB of flat gradients are NOT cleared per
         # step: a slice is zeroed only if its producer accumulates into it (the embedding scatter: `_kai0_grad_accumulates`)
         # or, lazily in the next step(), if it holds an old gradient and no new one arrived.
-        full = os.environ.get("KAI0_ZERO_GRADS") == "full"  # diagnostics: clear everything, as before
         for b in self.buckets:
-            if full and b.grad_resident:
-                b.flat_grad.zero_()
-                b.stale.clear()
             for p, o in zip(b.params, b.offsets):
                 if not b.grad_resident:  # fsdp staging buffer already given back: it comes back zero-filled (_ensure_grad)
                     break
-                if id(p) in b.arrived and not full:
+                if id(p) in b.arrived:
                     if getattr(p, "_kai0_grad_accumulates", False):
                         b.flat_grad[o : o + p.numel()].zero_()
                         b.stale.discard(id(p))

@@ -252,54 +252,50 @@ def test_wgrad_ring_gemm_production_shape():
     assert torch.isfinite(dw.float()).all()
 
 
-def test_fullwidth_chunk_switches_agree(fw, monkeypatch):
-    """At the real widths (where the in-block denoise kernels, the step-seam kernel and the pair GEMM actually run): the chunk with
-    the modulation table recomputed per call is bit-identical to the cached one; with the six-launch step seam instead of
-    kai0_denoise_glue it differs by the round-off of the seam's two f32 dots (amplified by the bf16 roundings downstream); with gate GEMM + up GEMM instead of the pair GEMM it is bit-identical."""
+def test_fullwidth_production_denoise_stack_agrees_with_the_generic_path(fw):
+    """At the real widths the chunk comes from the production stack (in-block weight-streaming kernels, adaRMS folded into per-step
+    weights, one-launch step seams, two-launch decode attention).  The generic per-layer path (plain GEMMs, adaRMS kernels, RoPE /
+    attention / Euler launches of their own — what other shapes run) must give the same chunk within the bf16 path's round-off: other
+    rounding points (weights rounded after the (1 + scale) factor instead of activations after the norm), inside the chunk tolerance.
+    Also: gate GEMM + up GEMM instead of the pair GEMM is bit-identical; the norms behind split-K Linears as launches of their own
+    differ by the summation order of the row statistics only."""
     from test_fullsize_gpu import _take
 
     from kai0_amd import ops
+    from kai0_amd.infer import InferenceEngine
 
     m, d = fw["model"], dev()
     m.eval()
     try:
         gobs, noise = _take(fw["gobs"], 1), fw["noise"][1:2].to(d)
+        m.invalidate_inference_engine()
         ref = m.sample_actions(d, gobs, noise=noise, num_steps=10)
         eng = m._engine
-        assert eng.glue and eng.cache_mods and eng.inblock and eng.decode_attn and eng.fold and eng._fold_cache
-        # round 4: the adaRMS norms folded into per-step weights (default) against the adaRMS-prologue kernels of round 3: other
-        # rounding points (weights rounded after the scale instead of activations after the norm), inside the chunk tolerance
-        monkeypatch.setenv("KAI0_INFER_FOLD", "0")
-        m.invalidate_inference_engine()
-        unfolded = m.sample_actions(d, gobs, noise=noise, num_steps=10)
-        print(f"chunk with folded adaRMS vs the prologue form: rel-L2 {rel(ref, unfolded):.3e}")
-        assert not m._engine.fold and rel(ref, unfolded) < 3e-3, rel(ref, unfolded)
-        monkeypatch.setenv("KAI0_INFER_CACHE_MODS", "0")  # (the table recomputed per call: no folding either)
-        m.invalidate_inference_engine()
-        assert torch.equal(m.sample_actions(d, gobs, noise=noise, num_steps=10), unfolded)
-        monkeypatch.setenv("KAI0_INFER_GLUE", "0")
-        m.invalidate_inference_engine()
-        six = m.sample_actions(d, gobs, noise=noise, num_steps=10)
-        # (the two f32 dots of a seam sum in another order; a flipped bf16 rounding then travels through 18 layers x 10 steps:
-        # measured 4.4e-4, an order of magnitude inside the chunk's tolerance against the oracle)
-        assert not m._engine.glue and rel(six, unfolded) < 2e-3, rel(six, unfolded)
-        monkeypatch.delenv("KAI0_INFER_CACHE_MODS")
-        monkeypatch.delenv("KAI0_INFER_GLUE")
-        monkeypatch.delenv("KAI0_INFER_FOLD")
+        assert eng.fast and eng.fuse_norm and eng._fold_cache
+        InferenceEngine.force_generic = True
+        try:
+            m.invalidate_inference_engine()
+            generic = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+            assert not m._engine.fast
+        finally:
+            InferenceEngine.force_generic = False
+        print(f"chunk: production stack vs generic per-layer path: rel-L2 {rel(ref, generic):.3e}")
+        assert rel(ref, generic) < 3e-3, rel(ref, generic)
         old = ops.set_geglu_pair(False)
         try:
             m.invalidate_inference_engine()
             assert torch.equal(m.sample_actions(d, gobs, noise=noise, num_steps=10), ref)
         finally:
             ops.set_geglu_pair(old)
-        # the norms behind the split-K Linears as launches of their own (kai0hip.h norm_kind off): same arithmetic, another
-        # summation order of the row statistics (block-wide instead of wave-wide)
-        assert m._engine.fuse_norm
-        monkeypatch.setenv("KAI0_INFER_FUSE_NORM", "0")
-        m.invalidate_inference_engine()
-        sep = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+        InferenceEngine.fuse_split_norm = False
+        try:
+            m.invalidate_inference_engine()
+            sep = m.sample_actions(d, gobs, noise=noise, num_steps=10)
+            assert not m._engine.fuse_norm
+        finally:
+            InferenceEngine.fuse_split_norm = True
         print(f"chunk with separate norm launches vs fused: rel-L2 {rel(sep, ref):.3e}")
-        assert not m._engine.fuse_norm and rel(sep, ref) < 2e-3, rel(sep, ref)
+        assert rel(sep, ref) < 2e-3, rel(sep, ref)
     finally:
         m.invalidate_inference_engine()
         m.train()
@@ -320,7 +316,7 @@ def test_fullwidth_engine_notices_a_weight_edit_behind_autograd(fw):
         before = m.sample_actions(d, gobs, noise=noise, num_steps=10)
         eng = m._engine
         torch.cuda.synchronize()
-        assert eng.skinny and not m.inference_is_stale()
+        assert eng.fast and not m.inference_is_stale()
         saved = w.data.clone()
         w.data.mul_(1.25)
         stale_chunk = m.sample_actions(d, gobs, noise=noise, num_steps=10)

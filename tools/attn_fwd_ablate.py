@@ -1,4 +1,5 @@
-"""One-pass attention forward at the training shape: ms per call (KAI0_ATTN_ABLATE bit mask removes phases; timing only)."""
+"""One-pass attention forward at the training shape: ms per call (KAI0_ATTN_ABLATE bit mask removes phases; timing only).
+Needs a library built with KAI0_HIPCC_FLAGS=-DKAI0_ABLATE (the shipped kernels carry no ablation branch)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kai0_amd import ops

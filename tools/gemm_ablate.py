@@ -1,4 +1,6 @@
-"""GEMM limiter probes: KAI0_GEMM_ABLATE=1 (no DMA in the K loop) and leading-dimension padding (channel conflicts)."""
+"""GEMM limiter probes: KAI0_GEMM_ABLATE=1 (no DMA in the K loop) and leading-dimension padding (channel conflicts).
+Needs a library built with the ablation hooks: KAI0_HIPCC_FLAGS=-DKAI0_ABLATE python -m kai0_amd.build --force (round 5: the shipped
+kernels carry none)."""
 import os, sys, subprocess
 if len(sys.argv) > 1:
     import torch
