@@ -141,6 +141,19 @@ typedef struct kai0_gemm_desc {
     const void* norm_b;
     float norm_eps;
     int32_t norm_kind;
+    /* act 7 — RoPE fused into the epilogue of a stacked q | k | v projection (round 5; the rotation the reference applies right after
+     * q_proj / k_proj: gemma_pytorch.py:185-195, apply_rotary_pos_emb modeling_gemma.py:149-194).  The partners of a rotation — columns
+     * j and j + rope_half of a head — must meet in one 128-column tile, so the caller passes B with its rows PERMUTED inside the rotated
+     * range: permuted column pc of [0, rope_n_end) is real column (pc / 256) * 256 + ((pc % 128) / 64) * 128 + 64 * ((pc % 256) / 128)
+     * + pc % 64 (every tile = 64 first-half columns of a head followed by their 64 partners); columns >= rope_n_end are not rotated
+     * and not permuted.  Epilogue: x = bf16(acc) (the Linear's output), then out1 = bf16(bf16(x1 cos) + bf16(-x2 sin)), out2 =
+     * bf16(bf16(x2 cos) + bf16(x1 sin)) — bit for bit kai0_gemm_bf16 followed by kai0_rope_inplace — stored at the REAL columns
+     * (seg[] boundaries are real columns).  rope_cos / rope_sin: bf16 [M][rope_half] (the values of kai0_rope_table; row = A row),
+     * rope_half = 128, rope_n_end % 256 == 0.  K-contiguous operands, one batch entry, no split-K, plain bf16 output; runs on the
+     * 128 x 128 configuration (meant for the B = 1 prefix pass, where the rotation's own launch cost more than its arithmetic). */
+    const void* rope_cos;
+    const void* rope_sin;
+    int32_t rope_half, rope_n_end;
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);

@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("rowvec", c_p), ("rv_s1", c_i64), ("rv_s2", c_i64), ("rv_ld", c_i64),
         ("B2", c_p), ("pre_out2", c_p),
         ("norm_out", c_p), ("norm_w", c_p), ("norm_b", c_p), ("norm_eps", C.c_float), ("norm_kind", C.c_int32),
+        ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("rope_n_end", C.c_int32),
     ]  # fmt: skip
 
 

@@ -95,6 +95,10 @@ struct GemmArgs {
     const bf16_t* norm_b;
     float norm_eps;
     int norm_kind;
+    // act 7 (RoPE epilogue, kai0hip.h): bf16 tables [M][rope_half]; permuted columns < rope_n_end are rotated
+    const bf16_t* rope_cos;
+    const bf16_t* rope_sin;
+    int rope_half, rope_n_end;
 };
 
 // LDS-DMA through a raw buffer descriptor: 16 B per lane from base + voff (bytes) to lds_dst + lane*16.  An offset at
@@ -830,6 +834,60 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                             !p.accumulate && !p.out_f32 && p.nseg == 0 && (N_ALIGNED8(p.N));
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
+        if constexpr (MT == 4 && WM == 2 && WN == 2 && A_KC && B_KC) if (p.act == 7) {
+            // RoPE epilogue (kai0hip.h act 7): the tile's columns are [64 first-half columns of a head | their 64 partners] (the caller
+            // permuted B's rows), i.e. the partner of this wave's column c is column c of the OTHER wave of its tile row (wave ^ 1).
+            // Accumulators -> the wave-private slabs, block barrier, then every lane reads its 8 columns from its own slab and the
+            // partners from the neighbour's.  The rotation's tables (bf16, the values of kai0_rope_table) for the lane's 8 rows are
+            // requested before the barrier.  Rounding points: x = bf16(acc), then exactly rope_kernel's (elementwise.hip).
+            const bool rot = n0 < p.rope_n_end;                                  // tile-uniform
+            const int fi = ((n0 >> 7) & 1) * 64 + (lane & 7) * 8;                // frequency index of the lane's 8 columns
+            const int rcol = rot ? (n0 >> 8) * 256 + wn * 128 + fi : n0 + wn * 64 + (lane & 7) * 8;   // REAL column
+            const int rbase = row_base(h) + (lane >> 3);
+            bf16x8 cs[8], sn[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t tr = (int64_t)min(rbase + it * 8, p.M - 1) * p.rope_half + fi;  // (clamped: unconditional loads)
+                cs[it] = *reinterpret_cast<const bf16x8*>(p.rope_cos + (rot ? tr : 0));
+                sn[it] = *reinterpret_cast<const bf16x8*>(p.rope_sin + (rot ? tr : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[i][j][r];
+            lds_barrier();
+            const float* pslab = reinterpret_cast<const float*>(smem + (wave ^ 1) * 16384);
+            int si = 0;
+            if (p.nseg > 1 && rcol >= p.seg_begin[1]) si = 1;
+            if (p.nseg > 2 && rcol >= p.seg_begin[2]) si = 2;
+            const bool rcol_ok = rcol < p.N;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 8 + (lane >> 3);
+                const int row = rbase + it * 8;
+                const int so = lr * 64 + (lane & 7) * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + so), v1 = *reinterpret_cast<const f32x4*>(slab + so + 4);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(pslab + so), w1 = *reinterpret_cast<const f32x4*>(pslab + so + 4);
+                if (row >= p.M || !rcol_ok) continue;
+                const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const float y[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xe = rbf(x[e]), ye = rbf(y[e]);
+                    const float c = bf2f(cs[it][e]), sv = bf2f(sn[it][e]);
+                    // first half (wn == 0): x1 cos - x2 sin;  second half: x2 cos + x1 sin  (rope_kernel's roundings)
+                    ov[e] = rot ? f2bf(rbf(xe * c) + rbf((wn == 0 ? -ye : ye) * sv)) : f2bf(xe);
+                }
+                const int64_t orow = p.cmap(row);
+                bf16_t* cp = p.nseg > 0 ? p.seg_dst[si] + orow * p.seg_ld[si] + (rcol - p.seg_begin[si])
+                                        : reinterpret_cast<bf16_t*>(p.C) + cz + orow * p.ldc + rcol;
+                *reinterpret_cast<bf16x8*>(cp) = ov;
+            }
+            return;
+        }
         if (pair) {
             // GeGLU in registers: slab columns [0, 32) = gate, [32, 64) = up of the wave's 32 output columns n0/2 + wn*32 + ..;
             // each lane takes 8 of them for one row (16 rows per pass).  Rounding points of act 2: g = bf16(acc), u = bf16(acc),
@@ -1640,7 +1698,14 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d->batch <= 1 || (((d->sA1 | d->sA2 | d->sB1 | d->sB2) & 7) == 0 && ((d->sC1 | d->sC2) & (d->out_f32 ? 3 : 7)) == 0),
                  "kai0_gemm_bf16: batch strides must be multiples of 8 elements (16 B)");
     KAI0_REQUIRE(d->gate == nullptr || d->gate_rpb > 0, "kai0_gemm_bf16: gate needs gate_rpb > 0");
-    KAI0_REQUIRE(d->act >= 0 && d->act <= 6, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act >= 0 && d->act <= 7, "kai0_gemm_bf16: unknown act %d", d->act);
+    KAI0_REQUIRE(d->act != 7 || (d->rope_cos && d->rope_sin && d->rope_half == 128 && d->rope_n_end > 0 && (d->rope_n_end % 256) == 0 &&
+                                 d->rope_n_end <= d->N && (d->N % 128) == 0 && d->a_kc && d->b_kc && d->batch <= 1 && d->split_k <= 1 &&
+                                 !d->out_f32 && !d->accumulate && !d->bias && !d->gate && !d->residual && !d->pre_out &&
+                                 (d->scale == 0.0f || d->scale == 1.0f) && d->b_rpb == 0 && ((uintptr_t)d->rope_cos % 16) == 0 &&
+                                 ((uintptr_t)d->rope_sin % 16) == 0),
+                 "kai0_gemm_bf16: act=7 (RoPE epilogue) needs bf16 cos / sin tables [M][128], rope_n_end %% 256 == 0, N %% 128 == 0, K-contiguous "
+                 "operands, one batch entry, no split-K, a plain bf16 output");
     KAI0_REQUIRE(d->act != 6 || (d->B2 && d->a_kc && d->b_kc && d->batch <= 1 && d->split_k <= 1 && !d->out_f32 && !d->accumulate &&
                                  d->nseg == 0 && !d->bias && !d->gate && !d->residual && (d->scale == 0.0f || d->scale == 1.0f) &&
                                  (d->N % 32) == 0 && d->b_rpb == 0 && ((uintptr_t)d->B2 % 16) == 0),
@@ -1660,7 +1725,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
                  "kai0_gemm_bf16: act=%d (fused GeGLU) needs pre_out and aux inputs, bf16 output", d->act);
     KAI0_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "kai0_gemm_bf16: nseg=%d", d->nseg);
     if (d->nseg > 0) {
-        KAI0_REQUIRE(!d->out_f32 && !d->accumulate && (d->batch <= 1) && d->act < 2 && !d->pre_out && (d->N % 8) == 0,
+        KAI0_REQUIRE(!d->out_f32 && !d->accumulate && (d->batch <= 1) && (d->act < 2 || d->act == 7) && !d->pre_out && (d->N % 8) == 0,
                      "kai0_gemm_bf16: column segments need a plain bf16 epilogue, batch 1");
         KAI0_REQUIRE(d->act != 4, "kai0_gemm_bf16: column segments and act=4 are exclusive");
         for (int i = 0; i < d->nseg; ++i)
@@ -1692,6 +1757,10 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     p.norm_b = (const bf16_t*)d->norm_b;
     p.norm_eps = d->norm_eps;
     p.norm_kind = d->norm_kind;
+    p.rope_cos = (const bf16_t*)d->rope_cos;
+    p.rope_sin = (const bf16_t*)d->rope_sin;
+    p.rope_half = d->rope_half;
+    p.rope_n_end = d->rope_n_end;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
     p.sA1 = d->sA1; p.sA2 = d->sA2; p.sB1 = d->sB1; p.sB2 = d->sB2; p.sC1 = d->sC1; p.sC2 = d->sC2;
@@ -1740,7 +1809,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
     const int forced = g_gemm_cfg;
     const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((p.N + 255) / 256) * batch * (split > 1 ? split : 1);
-    const bool big = forced ? forced >= 4 : (big_tiles >= 160 && d->K >= 256);
+    const bool big = d->act == 7 ? false : (forced ? forced >= 4 : (big_tiles >= 160 && d->K >= 256));  // (act 7: 128-column tiles)
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // measured on the MLP shapes: the ping-pong schedule wins for NT (+3..8 %) and loses for the transpose-read

@@ -187,6 +187,15 @@ class InferenceEngine:
         lm = self.pe.paligemma.model.language_model
         self.lm_wqkv = [torch.cat([l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight], 0).contiguous()
                         for l in lm.layers]  # fmt: skip
+        # round 5: RoPE in the epilogue of the prefix pass's q|k|v GEMM (kai0hip.h act 7) where that GEMM runs on 128-column tiles (the
+        # B = 1 pass: 18 launches of ~10 us fewer per chunk).  The rotation's partners (columns j, j + 128 of a head) must meet in one
+        # tile, so the stacked copy of every layer but the last (which only projects K / V) is kept with its rows permuted instead.
+        NQ = self.H * self.HD
+        self.fuse_rope = self.HD == 256 and self.B * self.P <= 1024 and _PREFIX_SPLITS[0] in (0, 1)
+        if self.fuse_rope:
+            perm = ops.rope_permutation(NQ + 2 * self.HD, NQ + self.HD).to(self.dev)
+            for l in range(self.L - 1):
+                self.lm_wqkv[l] = self.lm_wqkv[l][perm].contiguous()
 
     def _lin(self, x, w, *, bias=None, residual=None, act=0, split=None, aux1=None, norm=None):
         """flat Linear for the prefix / SigLIP passes: launches matter more than occupancy here, so the contraction is
@@ -355,6 +364,9 @@ class InferenceEngine:
         M = B * P
         lm_layers = list(lm.layers)
         hp = ops.rmsnorm(xp, lm_layers[0].input_layernorm.weight, lm_layers[0].input_layernorm.eps)
+        if self.fuse_rope:  # the rotation's tables for the prefix rows of this request, once per chunk (bf16: the values are bf16-rounded)
+            cs, sn = ops.rope_table(self.pos_prefix.reshape(-1), inv_freq)
+            rope_cos, rope_sin = ops.cast(cs, BF16), ops.cast(sn, BF16)
         for l, layer in enumerate(lm_layers):
             at = layer.self_attn
             if l == self.L - 1:
@@ -365,10 +377,14 @@ class InferenceEngine:
                 ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
                 break
             # stacked q|k|v projection written straight into the padded q buffer and the K / V caches
-            gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
-                 c_map=(P, S_ld, 0), segs=[(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)],
-                 split_k=_PREFIX_SPLITS[0] or 1)  # fmt: skip
-            ops.rope2_(self.q_buf, H, self.k_cache[l], 1, self.pos_prefix, inv_freq, B, P, S_ld, 0, HD)  # q and k: one launch
+            segs = [(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)]
+            if self.fuse_rope:  # ... rotated on the way out (rows of the stacked weight permuted, _build_stacked)
+                gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
+                     c_map=(P, S_ld, 0), segs=segs, act=7, rope=(rope_cos, rope_sin, HD // 2, NQ + HD))
+            else:
+                gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
+                     c_map=(P, S_ld, 0), segs=segs, split_k=_PREFIX_SPLITS[0] or 1)
+                ops.rope2_(self.q_buf, H, self.k_cache[l], 1, self.pos_prefix, inv_freq, B, P, S_ld, 0, HD)  # q and k: one launch
             self._attend(l, 0, P, P, qcode, kcode)
             pan = layer.post_attention_layernorm
             xp, hp = self._oproj(at.o_proj, P, 0, residual=xp, norm=(1, pan.weight, None, pan.eps))

@@ -55,7 +55,7 @@ def gemm(
     gate_rpb: int = 0, gate_ld: int = 0, residual: torch.Tensor | None = None, ldr: int = 0, sR=(0, 0),
     accumulate: bool = False, a_off_elems: int = 0, b_off_elems: int = 0, c_off_elems: int = 0, split_k: int = 1,
     aux1: torch.Tensor | None = None, aux2: torch.Tensor | None = None, segs=None, rowvec=None, rv=(0, 0, 1),
-    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None, norm=None, nt_out: bool = False,
+    B2: torch.Tensor | None = None, pre_out2: torch.Tensor | None = None, norm=None, nt_out: bool = False, rope=None,
 ) -> torch.Tensor:  # fmt: skip
     """kai0_gemm_bf16. `*_map` = (rows_per_batch, batch_stride_rows, row_offset). `*_off_elems` shift the base
     pointer (for column slices such as a head inside a fused projection)."""
@@ -90,6 +90,11 @@ def gemm(
     d.out_f32 = int(out_f32)
     d.pre_out = _p(pre_out)
     d.aux1, d.aux2 = _p(aux1), _p(aux2)
+    if rope is not None:  # act 7: (cos bf16 [M, half], sin bf16 [M, half], half, n_end) — B's rows permuted (rope_permutation)
+        rc, rs, half, n_end = rope
+        if rc.dtype != BF16 or rs.dtype != BF16 or not rc.is_contiguous() or not rs.is_contiguous() or rc.shape != (M, half) or rs.shape != (M, half):
+            raise TypeError("gemm: rope tables must be contiguous bf16 [M, half]")
+        d.rope_cos, d.rope_sin, d.rope_half, d.rope_n_end = rc.data_ptr(), rs.data_ptr(), half, n_end
     if B2 is not None:  # act 6: gate (B) | up (B2) weights of the GeGLU pair GEMM
         if B2.dtype != BF16 or not B2.is_cuda:
             raise TypeError("gemm: B2 must be a bf16 HIP tensor")
@@ -247,6 +252,16 @@ def rowdot(a, b, D: int):
     out = torch.empty((rows,), dtype=F32, device=a.device)
     _lib.call("kai0_rowdot_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, D, _stream())
     return out
+
+
+def rope_permutation(n_total: int, n_rope_end: int, half: int = 128) -> torch.Tensor:
+    """Row order of a stacked q | k | v weight for the RoPE epilogue of kai0_gemm_bf16 (act 7, kai0hip.h): permuted row pc holds real row
+    perm[pc]; inside [0, n_rope_end) every 128-row tile = 64 first-half rows of a head followed by their 64 partners."""
+    if half != 128 or n_rope_end % 256 != 0 or n_rope_end > n_total:
+        raise ValueError("rope_permutation: head_dim 256 (half 128), rotated range a whole number of heads")
+    pc = torch.arange(n_total)
+    real = (pc // 256) * 256 + ((pc % 128) // 64) * 128 + 64 * ((pc % 256) // 128) + pc % 64
+    return torch.where(pc < n_rope_end, real, pc)
 
 
 def rope_table(pos, inv_freq):

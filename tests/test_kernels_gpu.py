@@ -213,6 +213,38 @@ def test_gemm_batch_strides_may_be_negative_or_span_two_allocations(ops):
                  sA=(Bn * K * M, K * M), sB=(dist + 4, K * N), sC=(Bn * M * N, M * N))
 
 
+@pytest.mark.parametrize("B,P,S_ld,T", [(1, 968, 1024, 200), (2, 136, 160, 40)])
+def test_gemm_rope_epilogue_is_bit_identical_to_gemm_then_rope(ops, B, P, S_ld, T):
+    """act 7 (kai0hip.h): the stacked q | k | v projection of the B = 1 prefix pass with the rotation in its epilogue — weight rows
+    permuted so that a rotation's partners meet in one 128-column tile, output routed to the padded q buffer and the K / V caches at
+    the REAL columns — against the same GEMM followed by kai0_rope_inplace2: bit for bit, padding rows untouched."""
+    H, HD, D = 8, 256, 264
+    NQ, M = H * HD, B * P
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(M, D, generator=g) * 1.0).to(BF16).to(dev())
+    w = (torch.randn(NQ + 2 * HD, D, generator=g) * 0.06).to(BF16).to(dev())
+    pos = torch.stack([torch.cumsum((torch.rand(P, generator=g) > 0.1).int(), 0) - 1 for _ in range(B)]).clamp(min=0).to(torch.int32).to(dev())
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, HD, 2).float() / HD))).to(BF16).float().to(dev())
+
+    def bufs():
+        return (torch.full((B, S_ld, NQ), 3.0, dtype=BF16, device=dev()), torch.full((B, S_ld, HD), 3.0, dtype=BF16, device=dev()),
+                torch.full((B, S_ld, HD), 3.0, dtype=BF16, device=dev()))
+
+    q0, k0, v0 = bufs()
+    segs = lambda q, k, v: [(q, NQ, 0), (k, HD, NQ), (v, HD, NQ + HD)]  # noqa: E731
+    ops.gemm(x, w, q0, M=M, N=NQ + 2 * HD, K=D, lda=D, ldb=D, ldc=NQ, c_map=(P, S_ld, 0), segs=segs(q0, k0, v0))
+    ops.rope2_(q0, H, k0, 1, pos, inv_freq, B, P, S_ld, 0, HD)
+    q1, k1, v1 = bufs()
+    perm = ops.rope_permutation(NQ + 2 * HD, NQ + HD).to(dev())
+    cos, sin = ops.rope_table(pos.reshape(-1), inv_freq)
+    ops.gemm(x, w[perm].contiguous(), q1, M=M, N=NQ + 2 * HD, K=D, lda=D, ldb=D, ldc=NQ, c_map=(P, S_ld, 0), segs=segs(q1, k1, v1), act=7,
+             rope=(cos.to(BF16), sin.to(BF16), HD // 2, NQ + HD))
+    assert torch.equal(q1, q0) and torch.equal(k1, k0) and torch.equal(v1, v0)
+    assert float(q1[:, P:].float().min()) == 3.0 and float(k1[:, P:].float().min()) == 3.0  # padding rows untouched
+    ref = (x.float() @ w.float().t()).to(BF16).float().view(B, P, -1)
+    assert_close_bf16(v1[:, :P], ref[..., NQ + HD :], what="v segment")
+
+
 def test_gemm_n_not_multiple_of_8(ops):
     M, N, K, ld = 64, 20, 72, 24
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
