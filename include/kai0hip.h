@@ -444,6 +444,15 @@ typedef struct kai0_attn_desc {
     int64_t s_lse;    /* batch stride of lse (>= rows) */
 } kai0_attn_desc;
 int kai0_attn_fwd(const kai0_attn_desc* d, kai0_stream_t stream);
+/* Key-split attention (round 5; the B = 1 prefix pass of the action chunk: 61 row blocks cannot fill 256 CUs, 4 key ranges x 61 can).
+ * The caller runs kai0_attn_fwd once with `parts` key ranges as batch entries (batch = parts, batch_inner = 1: sQ1 = 0 and qcode_ld = 0
+ * share the queries, sK1 / sV1 / kcode_ld = the range length step K / V / the key codes, P = NULL, lse set) into o_parts
+ * [parts][rows][HD] bf16 and lse_parts [parts][lse_stride] f32; this call merges them: O[r] = sum_s w_s O_s[r] with
+ * w_s = exp(lse_s[r] - max) / sum_t exp(lse_t[r] - max) — the softmax over all keys (eager_attention_forward,
+ * modeling_gemma.py:230-253) evaluated range by range; f32 arithmetic, one bf16 rounding of O on top of the parts' own.  A row that
+ * saw no key in any range gets zeros.  O: row stride ldo (elements); parts <= 8; HD % 8 == 0. */
+int kai0_attn_combine(const void* o_parts, const float* lse_parts, void* O, int parts, int rows, int HD, int64_t ldo,
+                      int64_t part_stride, int64_t lse_stride, kai0_stream_t stream);
 int kai0_attn_desc_size(void); /* sizeof(kai0_attn_desc) */
 
 /* ------------------------------------------------------------------------------------------------

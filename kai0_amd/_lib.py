@@ -125,6 +125,7 @@ _PROTOS: dict[str, list] = {
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "kai0_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "kai0_attn_desc_size": [],
+    "kai0_attn_combine": [c_p, c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_p],
     "kai0_attn_bwd_dq2": [C.POINTER(AttnBwdDesc), c_p],
     "kai0_attn_bwd_desc_size": [],
     "kai0_siglip_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_p],

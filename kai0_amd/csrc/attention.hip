@@ -612,7 +612,57 @@ __global__ __launch_bounds__(RB / (16 * QT) * 64, RB == 64 ? 2 : 1) void attn_fw
     }
 }
 
+// Key-split attention, second half: `parts` one-pass launches of attn_fwd_kernel over disjoint key ranges left per range the
+// range-normalised output O_s (bf16) and the range's log-sum-exp lse_s (+inf: the row saw no key in the range).  The softmax over all
+// keys is the lse-weighted mean: O = sum_s w_s O_s, w_s = exp(lse_s - m) / sum_t exp(lse_t - m), m = max lse.  One thread = 8 head-dim
+// columns of one row; f32 arithmetic, one rounding of O.  A row that saw no key in any range gets zeros (as the one-range kernel does).
+__global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restrict__ Op, const float* __restrict__ lse, bf16_t* __restrict__ O,
+                                                           int parts, int rows, int HD, int64_t ldo, int64_t part_stride, int64_t lse_stride) {
+    const int cpr = HD >> 3;  // 8-column chunks per row
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)rows * cpr) return;
+    const int r = (int)(t / cpr), c = (int)(t - (int64_t)r * cpr) * 8;
+    float l[8], m = -INFINITY;
+    bf16x8 v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < parts) {  // (parts <= 8: unrolled, every load of the thread in flight together)
+            l[s] = lse[(int64_t)s * lse_stride + r];
+            v[s] = *reinterpret_cast<const bf16x8*>(Op + (int64_t)s * part_stride + (int64_t)r * HD + c);
+            if (l[s] < INFINITY) m = fmaxf(m, l[s]);
+        }
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < parts) {
+            const float w = (l[s] < INFINITY) ? __expf(l[s] - m) : 0.f;
+            wsum += w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w * bf2f(v[s][e]);
+        }
+    }
+    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv);
+    *reinterpret_cast<bf16x8*>(O + (int64_t)r * ldo + c) = o;
+}
+
 }  // namespace
+
+KAI0_API int kai0_attn_combine(const void* o_parts, const float* lse_parts, void* O, int parts, int rows, int HD, int64_t ldo,
+                               int64_t part_stride, int64_t lse_stride, kai0_stream_t stream) {
+    KAI0_REQUIRE(o_parts && lse_parts && O, "kai0_attn_combine: null operand");
+    KAI0_REQUIRE(parts >= 1 && parts <= 8 && HD % 8 == 0 && HD > 0 && ldo % 8 == 0 && part_stride % 8 == 0 && lse_stride >= rows &&
+                     ((uintptr_t)o_parts % 16) == 0 && ((uintptr_t)O % 16) == 0,
+                 "kai0_attn_combine: 1..8 parts, HD %% 8 == 0, 16-byte aligned rows");
+    if (rows <= 0) return 0;
+    const int64_t n = (int64_t)rows * (HD / 8);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)o_parts,
+                       lse_parts, (bf16_t*)O, parts, rows, HD, ldo, part_stride, lse_stride);
+    return kai0_check_launch("kai0_attn_combine");
+}
 
 KAI0_API int kai0_attn_desc_size(void) { return (int)sizeof(kai0_attn_desc); }
 

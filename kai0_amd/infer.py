@@ -58,6 +58,7 @@ class InferenceEngine:
     # shapes the production stack would take, and the norms behind split-K Linears as launches of their own
     force_generic = False
     fuse_split_norm = True
+    key_split = True  # B = 1 prefix attention as four key ranges of the one-pass kernel + merge (False: GEMM + softmax + GEMM)
 
     def __init__(self, model, batch: int, n_lang: int, n_cam: int):
         self.model = model
@@ -302,6 +303,12 @@ class InferenceEngine:
                          batch=B, ldq=HD, ldk=HD, ldv=HD, ldo=HD, sQ=(S_ld * H * HD, 0), sK=(S_ld * HD, 0),
                          sV=(S_ld * HD, 0), sO=(S_ld * H * HD, 0), qcode=qcode, kcode=kcode, scale=HD**-0.5,
                          q_off=q0 * H * HD, o_off=q0 * H * HD)
+            return
+        if B == 1 and self.key_split and Sq > 128 and HD == 256 and Sk % 4 == 0 and Sk >= 512 and q0 == 0:
+            # the B = 1 prefix pass (round 5): the one-pass kernel over four key ranges (244 blocks instead of 61) + the lse-weighted
+            # merge — two launches and no logits / probabilities in memory instead of logits GEMM, softmax, split-K P V (+ reduce)
+            ops.attn_fwd_keysplit(self.q_buf, self.k_cache[l], self.v_cache[l], self.att_buf, rows=M, Sk=Sk, HD=HD, H=H, q0=q0, ldk=HD, ldv=HD,
+                                  qcode=qcode[0], kcode=kcode[0], scale=HD**-0.5, q_off=q0 * H * HD, o_off=q0 * H * HD, parts=4)
             return
         # latency-bound small batch: the key dimension has to be spread over the chip -> logits GEMM (N = keys),
         # masked softmax, split-K P V GEMM

@@ -1293,6 +1293,30 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def attn_fwd_keysplit(Q, K, V, O, *, rows, Sk, HD, H, q0, ldk, ldv, qcode, kcode, scale, q_off, o_off, parts: int = 4):
+    """One batch entry's masked attention with the keys cut into `parts` equal ranges (kai0_attn_fwd over the ranges as batch
+    entries + kai0_attn_combine): for grids whose row blocks alone cannot fill the chip (the B = 1 prefix pass).  Q rows are the folded
+    (position, head) rows at Q + q_off, contiguous [rows, HD]; O likewise at O + o_off; qcode / kcode 1-D views of this entry's codes."""
+    if Sk % parts != 0:
+        raise ValueError("attn_fwd_keysplit: Sk must be a multiple of the number of key ranges")
+    rng = Sk // parts
+    dev = Q.device
+    o_parts = torch.empty((parts, rows, HD), dtype=BF16, device=dev)
+    lse = torch.empty((parts, rows), dtype=torch.float32, device=dev)
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = Q.data_ptr() + 2 * q_off, K.data_ptr(), V.data_ptr(), o_parts.data_ptr()
+    d.qcode, d.kcode = _p(qcode), _p(kcode)
+    d.rows, d.Sk, d.HD, d.H, d.q0, d.batch, d.batch_inner = rows, rng, HD, H, q0, parts, 1
+    d.ldq, d.ldk, d.ldv, d.ldo = HD, ldk, ldv, HD
+    d.sQ1, d.sK1, d.sV1, d.sO1 = 0, rng * ldk, rng * ldv, rows * HD
+    d.qcode_ld, d.kcode_ld = 0, rng
+    d.scale = scale
+    d.online = 1
+    d.lse, d.s_lse = lse.data_ptr(), rows
+    _lib.call("kai0_attn_fwd", C.byref(d), _stream())
+    _lib.call("kai0_attn_combine", o_parts.data_ptr(), lse.data_ptr(), O.data_ptr() + 2 * o_off, parts, rows, HD, HD, rows * HD, rows, _stream())
+
+
 def attn_fwd(Q, K, V, O, P, *, rows, Sk, HD, H=1, q0=0, batch=1, batch_inner=1, ldq, ldk, ldv, ldo, ldp=0, sQ=(0, 0),
              sK=(0, 0), sV=(0, 0), sO=(0, 0), sP=0, qcode=None, kcode=None, scale, q_off=0, o_off=0, lse=None, online=0):
     """kai0_attn_fwd (fused logits + mask + softmax + P V).  P: optional probabilities output (the exact two-pass form);

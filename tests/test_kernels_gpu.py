@@ -1018,6 +1018,43 @@ def test_attn_decode_matches_gemm_softmax_gemm(ops, B, Hs, P):
     assert rel_err(out[:, P:S], gt) < 4e-3
 
 
+@pytest.mark.parametrize("P,valid", [(968, 861), (512, 40)])
+def test_attention_key_split_matches_the_one_range_kernel_and_fp32(ops, P, valid):
+    """The B = 1 prefix attention as four key ranges of the one-pass kernel + kai0_attn_combine (kai0hip.h) against the same kernel over
+    all keys in one range (same rounding points up to the ranges' own bf16 outputs) and against an fp32 softmax with the reference's
+    rounding of the logits: prefix-LM codes with padded prompt slots — whole ranges / key tiles of invisible keys when only 40 of the
+    512 positions are valid — and padded query rows (which must come out as zeros)."""
+    from kai0_amd.model import build_mask_codes
+
+    H, HD, S_ld = 8, 256, 1024
+    q = rnd(1, S_ld, H * HD, seed=1)
+    k = rnd(1, S_ld, HD, seed=2)
+    v = rnd(1, S_ld, HD, seed=3)
+    pad = torch.zeros(1, P, dtype=torch.bool)
+    pad[:, :valid] = True
+    pad[:, 5] = False  # a hole in the middle as well
+    qcode, kcode, _ = build_mask_codes(pad.to(dev()), torch.zeros(1, P, dtype=torch.bool, device=dev()))
+    M = P * H
+    one = torch.zeros(1, S_ld, H * HD, dtype=BF16, device=dev())
+    ops.attn_fwd(q, k, v, one, None, rows=M, Sk=P, HD=HD, H=H, q0=0, batch=1, ldq=HD, ldk=HD, ldv=HD, ldo=HD, sQ=(S_ld * H * HD, 0),
+                 sK=(S_ld * HD, 0), sV=(S_ld * HD, 0), sO=(S_ld * H * HD, 0), qcode=qcode, kcode=kcode, scale=HD**-0.5, online=1)
+    out = torch.full((1, S_ld, H * HD), 7.0, dtype=BF16, device=dev())
+    ops.attn_fwd_keysplit(q, k, v, out, rows=M, Sk=P, HD=HD, H=H, q0=0, ldk=HD, ldv=HD, qcode=qcode[0], kcode=kcode[0], scale=HD**-0.5,
+                          q_off=0, o_off=0, parts=4)
+    assert float(out[:, P:].float().min()) == 7.0  # rows past the queries untouched
+    qf = q[:, :P].float().view(1, P, H, HD)
+    logits = (torch.einsum("bshd,bkd->bshk", qf, k[:, :P].float()).to(BF16).float() * HD**-0.5).to(BF16).float()
+    allowed = kcode[:, None, :P] <= qcode[:, :P, None]
+    logits = logits.masked_fill(~allowed[:, :, None, :], float("-inf"))
+    pr = torch.nan_to_num(torch.softmax(logits, -1), nan=0.0)
+    gt = torch.einsum("bshk,bkd->bshd", pr, v[:, :P].float()).reshape(1, P, H * HD)
+    live = pad[0].to(dev())
+    assert float(out[0, :P][~live].float().abs().max()) == 0.0  # padded query rows: zeros
+    r_one, r_gt = rel_err(out[0, :P][live], one[0, :P][live]), rel_err(out[0, :P][live], gt[0][live])
+    print(f"key split vs one range {r_one:.3e}, vs fp32 softmax {r_gt:.3e}; one range vs fp32 {rel_err(one[0, :P][live], gt[0][live]):.3e}")
+    assert r_one < 4e-3 and r_gt < 4e-3
+
+
 def test_skinny_transposed_value_segment(ops):
     B, Hs, P, S_ld, HD, K = 2, 50, 30, 96, 256, 1024
     M = B * Hs
