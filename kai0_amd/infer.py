@@ -35,6 +35,11 @@ logger = logging.getLogger("kai0_amd")
 # the post-attention RMSNorm inside o_proj's reduction launch (kai0hip.h norm_kind) a split o_proj costs no extra launch: 1,2,6 ->
 # 5.56 against 5.68 ms for 1,1,6 (3 and 4: 5.58 / 5.59)
 _PREFIX_SPLITS = [int(x) for x in os.environ.get("KAI0_PREFIX_SPLITS", "1,2,6").split(",")]
+# split-K of the SigLIP tower's two narrow-output Linears at B = 1 (M = 3 x 256 rows; (M, N, K) -> split), swept on MI355X in round 5
+# (one gpurun call, p50 of the tower): out_proj 54 tiles x 18 K-tiles unsplit + a LayerNorm launch -> three chunks with the norm inside the
+# reduction launch; fc2 (K = 4304) five chunks on the two-stage configuration (270 blocks) -> four (216 blocks, <= one per CU: the
+# four-stage loop): tower 2.97 -> 2.77 ms
+_B1_SPLITS = {(768, 1152, 1152): 3, (768, 1152, 4304): 4}
 
 
 def NQ_ok(nq: int) -> bool:
@@ -207,7 +212,7 @@ class InferenceEngine:
         N = w.shape[0]
         if split is None:
             tiles = ((M + 127) // 128) * ((N + 127) // 128)
-            split = 1 if tiles >= 100 else pick_split_k(M, N, K)
+            split = _B1_SPLITS.get((M, N, K)) or (1 if tiles >= 100 else pick_split_k(M, N, K))
         out = torch.empty((M, N), dtype=BF16, device=self.dev)
         fused = None
         if norm is not None and self.fuse_norm and split > 1 and N <= 2048 and N % 8 == 0 and act == 0:
