@@ -64,6 +64,7 @@ class InferenceEngine:
     force_generic = False
     fuse_split_norm = True
     key_split = True  # B = 1 prefix attention as four key ranges of the one-pass kernel + merge (False: GEMM + softmax + GEMM)
+    overlap_step0 = True  # the first Euler step's chain on a second stream behind the prefix pass, layer by layer
 
     def __init__(self, model, batch: int, n_lang: int, n_cam: int):
         self.model = model
@@ -353,7 +354,8 @@ class InferenceEngine:
         return out, (ops.rmsnorm(out, norm[1], norm[3]) if norm[0] == 1 else ops.layernorm(out, norm[1], norm[2], norm[3]))
 
     # ------------------------------------------------------------------------------------------------ passes
-    def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks):
+    def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks, kv_ready=None):
+        # kv_ready(l): called right after layer l's K / V rows (rotated) are in the caches — the first denoise step may start on them
         model, pe = self.model, self.pe
         B, P, Hs = self.B, self.P, self.Hs
         prefix, ppad, patt = self._embed_prefix(images, img_masks, lang_tokens, lang_masks)
@@ -387,6 +389,8 @@ class InferenceEngine:
                      c_map=(P, S_ld, 0), segs=[(self.k_cache[l], HD, 0), (self.v_cache[l], HD, HD)],
                      split_k=pick_split_k(M, 2 * HD, self.Dp))  # fmt: skip
                 ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
+                if kv_ready is not None:
+                    kv_ready(l)
                 break
             # stacked q|k|v projection written straight into the padded q buffer and the K / V caches
             segs = [(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)]
@@ -397,6 +401,8 @@ class InferenceEngine:
                 gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
                      c_map=(P, S_ld, 0), segs=segs, split_k=_PREFIX_SPLITS[0] or 1)
                 ops.rope2_(self.q_buf, H, self.k_cache[l], 1, self.pos_prefix, inv_freq, B, P, S_ld, 0, HD)  # q and k: one launch
+            if kv_ready is not None:
+                kv_ready(l)
             self._attend(l, 0, P, P, qcode, kcode)
             pan = layer.post_attention_layernorm
             xp, hp = self._oproj(at.o_proj, P, 0, residual=xp, norm=(1, pan.weight, None, pan.eps))
@@ -465,44 +471,48 @@ class InferenceEngine:
         c0 = idx * 3 * De + 2 * De
         return self._gates[rows, c0 : c0 + De]
 
-    def _expert_stack_folded(self, xs, sq, step: int, rows, folded):
-        """All expert layers of one denoise step, 6 launches per layer and no partial products: [q|k|v + RoPE], logits, softmax + P V,
-        [o_proj + gated residual], [gate|up + GeGLU], [down_proj + gated residual], with the adaRMS norms folded into the weights: the
-        projections read the raw residual stream, the producers (denoise glue, o_proj, down_proj) hand the rows' partial sums of
-        squares along (`sq`: [64, M] f32, `parts` valid); the gates are precomputed for all steps (`_gate`)."""
+    def _expert_layer_folded(self, l: int, xs, sq, parts: int, step: int, rows, folded):
+        """Expert layer `l` of one denoise step, 6 launches and no partial products: [q|k|v + RoPE], logits, softmax + P V, [o_proj +
+        gated residual], [gate|up + GeGLU], [down_proj + gated residual], with the adaRMS norms folded into the weights: the projections
+        read the raw residual stream, the producers (denoise glue, o_proj, down_proj) hand the rows' partial sums of squares along (`sq`:
+        [parts, M] f32); the gates are precomputed for all steps (`_gate`).  Returns (xs, sq, parts) for the next layer."""
         B, P, Hs, De, H, HD, S_ld, F = self.B, self.P, self.Hs, self.De, self.H, self.HD, self.S_ld, self.F
         M, dev = B * Hs, self.dev
         cos, sin = self._rope_cs
-        layers = self.pe.gemma_expert.model.layers
+        layer = self.pe.gemma_expert.model.layers[l]
         NQ = H * HD
         ld = self._mod_ld
+        (wq, cq), (wg, cg) = folded[step][l]
+        ops.skinny_gemm(xs, wq, M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2, split_k=-1,
+                        segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
+                              (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
+                        c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, eps=layer.input_layernorm.eps,
+                        w_packed=True, rowsq_in=sq, rowsq_parts=parts, cvec=cq)  # fmt: skip
+        ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
+                        rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
+                        vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
+        x1 = torch.empty((M, De), dtype=BF16, device=dev)
+        sq1 = torch.empty((De // 16, M), dtype=F32, device=dev)
+        ops.skinny_gemm(self.att_buf, self.w_o[l], M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
+                        a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
+                        residual=xs, ldr=De, w_packed=True, rowsq_out=sq1)  # fmt: skip
+        h = torch.empty((M, F), dtype=BF16, device=dev)
+        ops.skinny_gemm(x1, wg, M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
+                        segs=[(h, F, 0, F, 0)], eps=layer.post_attention_layernorm.eps, w_packed=True,
+                        rowsq_in=sq1, rowsq_parts=De // 16, cvec=cg)  # fmt: skip
+        xs = torch.empty((M, De), dtype=BF16, device=dev)
+        sq = torch.empty((De // 16, M), dtype=F32, device=dev)
+        ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
+                        gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=True,
+                        rowsq_out=sq)  # fmt: skip
+        return xs, sq, De // 16
+
+    def _expert_stack_folded(self, xs, sq, step: int, rows, folded):
+        """All expert layers of one denoise step (the step seam, kai0_denoise_glue, applies the final norm)."""
         parts = 1  # the step's first rows come from the glue kernel: one partial per row
-        for l, layer in enumerate(layers):
-            (wq, cq), (wg, cg) = folded[step][l]
-            ops.skinny_gemm(xs, wq, M=M, N=NQ + 2 * HD, K=De, lda=De, ldw=De, mode=1, pair_stride=HD // 2, split_k=-1,
-                            segs=[(self.q_buf, NQ, 0, NQ, 1), (self.k_cache[l], HD, NQ, NQ + HD, 1),
-                                  (self.vt_all[l], S_ld, NQ + HD, NQ + 2 * HD, 2)],
-                            c_map=(Hs, S_ld, P), rope_cos=cos, rope_sin=sin, rope_half=HD // 2, eps=layer.input_layernorm.eps,
-                            w_packed=True, rowsq_in=sq, rowsq_parts=parts, cvec=cq)  # fmt: skip
-            ops.attn_decode(self.q_buf, self.k_cache[l], self.vt_all[l], self.att_buf, self.qcode, self.kcode, batch=B,
-                            rows=Hs * H, H=H, HD=HD, Sk=P + Hs, q0=P, q_bs=S_ld * NQ, k_bs=S_ld * HD, k_ld=HD, k_rows=S_ld,
-                            vt_bs=HD * S_ld, vt_ld=S_ld, scale=HD**-0.5)  # fmt: skip
-            x1 = torch.empty((M, De), dtype=BF16, device=dev)
-            sq1 = torch.empty((De // 16, M), dtype=F32, device=dev)
-            ops.skinny_gemm(self.att_buf, self.w_o[l], M=M, N=De, K=NQ, lda=NQ, ldw=NQ, split_k=-1,
-                            a_map=(Hs, S_ld, P), segs=[(x1, De, 0, De, 0)], gate=self._gate(2 * l, rows), gate_rpb=Hs, gate_ld=ld,
-                            residual=xs, ldr=De, w_packed=True, rowsq_out=sq1)  # fmt: skip
-            h = torch.empty((M, F), dtype=BF16, device=dev)
-            ops.skinny_gemm(x1, wg, M=M, N=2 * F, K=De, lda=De, ldw=De, mode=2, pair_stride=F, split_k=-1,
-                            segs=[(h, F, 0, F, 0)], eps=layer.post_attention_layernorm.eps, w_packed=True,
-                            rowsq_in=sq1, rowsq_parts=De // 16, cvec=cg)  # fmt: skip
-            xs = torch.empty((M, De), dtype=BF16, device=dev)
-            sq = torch.empty((De // 16, M), dtype=F32, device=dev)
-            ops.skinny_gemm(h, self.w_d[l], M=M, N=De, K=F, lda=F, ldw=F, split_k=-1, segs=[(xs, De, 0, De, 0)],
-                            gate=self._gate(2 * l + 1, rows), gate_rpb=Hs, gate_ld=ld, residual=x1, ldr=De, w_packed=True,
-                            rowsq_out=sq)  # fmt: skip
-            parts = De // 16
-        return xs  # the step seam (kai0_denoise_glue) applies the final norm
+        for l in range(self.L):
+            xs, sq, parts = self._expert_layer_folded(l, xs, sq, parts, step, rows, folded)
+        return xs
 
     def _denoise_step(self, x_t, step: int, mods, mf):
         """One Euler step on the generic path (shapes the production stack was not built for): per layer adaRMS, three projection
@@ -540,41 +550,82 @@ class InferenceEngine:
         dt = float(np.float32(-1.0 / num_steps))
         if tuple(times) not in self._times_dev:  # H2D copy: must happen outside graph capture (warm-up run)
             self._times_dev[tuple(times)] = torch.tensor(times, dtype=F32).repeat_interleave(self.B).to(self.dev)
-        self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
+        # the modulation table (and, production stack: the folded per-step weights) of this schedule: a function of the weights and the
+        # schedule only — computed on the first (warm-up) run, kept for the engine's lifetime
         hit = self._mods_cache.get(tuple(times))
-        if hit is None:  # first (warm-up) run of this schedule: computed eagerly, kept for the engine's lifetime
+        if hit is None:
             mods, mf = self._modulations(times)
             hit = self._mods_cache[tuple(times)] = (mods, mf, self._mod_ld if self.fast else None, self._gates if self.fast else None)
             if self.fast:
                 self._fold_cache[tuple(times)] = self._fold_modulations(mods, len(times))
         mods, mf = hit[0], hit[1]
         x_t = noise.clone().contiguous()
-        if self.fast:
+        if not self.fast:
+            self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
+        else:
             self._mod_ld, self._gates = hit[2], hit[3]
-            self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
-            # prefix value rows of every layer -> transposed cache, one launch
-            ops.transpose_strided(self.v_all, self.vt_all, R=self.P, C=self.HD, src_ld=self.HD, dst_ld=self.S_ld,
-                                  batch=self.L * self.B, src_bs=self.S_ld * self.HD, dst_bs=self.HD * self.S_ld)
             # step seams in one launch each (kai0_denoise_glue): [final adaRMS -> action_out_proj -> Euler update] of step s and
             # [action_in_proj -> bf16 + the rows' sums of squares] of step s + 1
-            model, B, Hs, De = self.model, self.B, self.Hs, self.De
+            model, B, Hs, De, P, HD, S_ld = self.model, self.B, self.Hs, self.De, self.P, self.HD, self.S_ld
             M, n = B * Hs, len(times)
             x2 = x_t.view(M, self.A)
             win, bin_ = model.action_in_proj.weight, model.action_in_proj.bias
             wout, bout = model.action_out_proj.weight, model.action_out_proj.bias
             eps = self.pe.gemma_expert.model.norm.eps
-            xs = torch.empty((M, De), dtype=BF16, device=self.dev)
             folded = self._fold_cache[tuple(times)]
-            sq = torch.empty((1, M), dtype=F32, device=self.dev)
-            ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs, rowsq_next=sq)
-            for step in range(n):
-                rows = slice(step * B, (step + 1) * B)
-                last = self._expert_stack_folded(xs, sq, step, rows, folded)
-                xs = torch.empty((M, De), dtype=BF16, device=self.dev) if step + 1 < n else None
-                sq = torch.empty((1, M), dtype=F32, device=self.dev) if xs is not None else None
-                ops.denoise_glue(x2, xs=last, mod=mf[rows], mod_ld=self._mod_ld, rows_per_batch=Hs, eps=eps, w_out=wout, b_out=bout,
-                                 dt=dt, w_in=win if xs is not None else None, b_in=bin_ if xs is not None else None, xs_next=xs,
-                                 rowsq_next=sq)
+            rows0 = slice(0, B)
+
+            def first_rows():
+                self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
+                xs0 = torch.empty((M, De), dtype=BF16, device=self.dev)
+                sq0 = torch.empty((1, M), dtype=F32, device=self.dev)
+                ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs0, rowsq_next=sq0)
+                return xs0, sq0
+
+            def transpose_v(l0, nl):  # prefix value rows of layers [l0, l0 + nl) -> transposed cache, one launch
+                ops.transpose_strided(self.v_all[l0:], self.vt_all[l0:], R=P, C=HD, src_ld=HD, dst_ld=S_ld, batch=nl * B,
+                                      src_bs=S_ld * HD, dst_bs=HD * S_ld)
+
+            if self.overlap_step0 and self.dev.type == "cuda":
+                # Round 5: layer l of the FIRST Euler step needs of the prefix pass only layer l's K / V rows, which exist ~300 us
+                # (one prefix layer) before layer l + 1's do, while a denoise layer is ~42 us of latency-bound launches that leave
+                # most of the chip idle: the first step's chain runs on a second stream behind the prefix pass, layer by layer
+                # (an event per layer; in the captured graph: a second branch), and is done ~one denoise layer after the prefix pass.
+                main = torch.cuda.current_stream()
+                side = self.__dict__.get("_side") or self.__dict__.setdefault("_side", torch.cuda.Stream())
+                st = {}
+
+                def kv_ready(l):
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        if l == 0:
+                            st["xs"], st["sq"] = first_rows()
+                            st["parts"] = 1
+                        transpose_v(l, 1)
+                        st["xs"], st["sq"], st["parts"] = self._expert_layer_folded(l, st["xs"], st["sq"], st["parts"], 0, rows0, folded)
+
+                self._prefix_pass(images, img_masks, lang_tokens, lang_masks, kv_ready=kv_ready)
+                main.wait_stream(side)
+                last = st["xs"]
+                last.record_stream(main)
+                first_step = 1
+            else:
+                self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
+                transpose_v(0, self.L)
+                xs, sq = first_rows()
+                last, first_step = None, 0
+            for step in range(first_step, n + 1):
+                if step > 0:  # the seam behind step - 1 (and in front of `step`, if there is one)
+                    more = step < n
+                    xs = torch.empty((M, De), dtype=BF16, device=self.dev) if more else None
+                    sq = torch.empty((1, M), dtype=F32, device=self.dev) if more else None
+                    r_prev = slice((step - 1) * B, step * B)
+                    ops.denoise_glue(x2, xs=last, mod=mf[r_prev], mod_ld=self._mod_ld, rows_per_batch=Hs, eps=eps, w_out=wout, b_out=bout,
+                                     dt=dt, w_in=win if more else None, b_in=bin_ if more else None, xs_next=xs, rowsq_next=sq)
+                if step < n:
+                    last = self._expert_stack_folded(xs, sq, step, slice(step * B, (step + 1) * B), folded)
             self._content_stamp()
             return x_t
         for step in range(len(times)):
