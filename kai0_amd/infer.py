@@ -64,7 +64,6 @@ class InferenceEngine:
     force_generic = False
     fuse_split_norm = True
     key_split = True  # B = 1 prefix attention as four key ranges of the one-pass kernel + merge (False: GEMM + softmax + GEMM)
-    overlap_step0 = True  # the first Euler step's chain on a second stream behind the prefix pass, layer by layer
 
     def __init__(self, model, batch: int, n_lang: int, n_cam: int):
         self.model = model
@@ -354,8 +353,7 @@ class InferenceEngine:
         return out, (ops.rmsnorm(out, norm[1], norm[3]) if norm[0] == 1 else ops.layernorm(out, norm[1], norm[2], norm[3]))
 
     # ------------------------------------------------------------------------------------------------ passes
-    def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks, kv_ready=None):
-        # kv_ready(l): called right after layer l's K / V rows (rotated) are in the caches — the first denoise step may start on them
+    def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks):
         model, pe = self.model, self.pe
         B, P, Hs = self.B, self.P, self.Hs
         prefix, ppad, patt = self._embed_prefix(images, img_masks, lang_tokens, lang_masks)
@@ -389,8 +387,6 @@ class InferenceEngine:
                      c_map=(P, S_ld, 0), segs=[(self.k_cache[l], HD, 0), (self.v_cache[l], HD, HD)],
                      split_k=pick_split_k(M, 2 * HD, self.Dp))  # fmt: skip
                 ops.rope_(self.k_cache[l], self.pos_prefix, inv_freq, B, P, S_ld, 0, 1, HD)
-                if kv_ready is not None:
-                    kv_ready(l)
                 break
             # stacked q|k|v projection written straight into the padded q buffer and the K / V caches
             segs = [(self.q_buf, NQ, 0), (self.k_cache[l], HD, NQ), (self.v_cache[l], HD, NQ + HD)]
@@ -401,8 +397,6 @@ class InferenceEngine:
                 gemm(hp, self.lm_wqkv[l], self.q_buf, M=M, N=NQ + 2 * HD, K=self.Dp, lda=self.Dp, ldb=self.Dp, ldc=NQ,
                      c_map=(P, S_ld, 0), segs=segs, split_k=_PREFIX_SPLITS[0] or 1)
                 ops.rope2_(self.q_buf, H, self.k_cache[l], 1, self.pos_prefix, inv_freq, B, P, S_ld, 0, HD)  # q and k: one launch
-            if kv_ready is not None:
-                kv_ready(l)
             self._attend(l, 0, P, P, qcode, kcode)
             pan = layer.post_attention_layernorm
             xp, hp = self._oproj(at.o_proj, P, 0, residual=xp, norm=(1, pan.weight, None, pan.eps))
@@ -573,50 +567,19 @@ class InferenceEngine:
             wout, bout = model.action_out_proj.weight, model.action_out_proj.bias
             eps = self.pe.gemma_expert.model.norm.eps
             folded = self._fold_cache[tuple(times)]
-            rows0 = slice(0, B)
-
-            def first_rows():
-                self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
-                xs0 = torch.empty((M, De), dtype=BF16, device=self.dev)
-                sq0 = torch.empty((1, M), dtype=F32, device=self.dev)
-                ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs0, rowsq_next=sq0)
-                return xs0, sq0
-
-            def transpose_v(l0, nl):  # prefix value rows of layers [l0, l0 + nl) -> transposed cache, one launch
-                ops.transpose_strided(self.v_all[l0:], self.vt_all[l0:], R=P, C=HD, src_ld=HD, dst_ld=S_ld, batch=nl * B,
-                                      src_bs=S_ld * HD, dst_bs=HD * S_ld)
-
-            if self.overlap_step0 and self.dev.type == "cuda":
-                # Round 5: layer l of the FIRST Euler step needs of the prefix pass only layer l's K / V rows, which exist ~300 us
-                # (one prefix layer) before layer l + 1's do, while a denoise layer is ~42 us of latency-bound launches that leave
-                # most of the chip idle: the first step's chain runs on a second stream behind the prefix pass, layer by layer
-                # (an event per layer; in the captured graph: a second branch), and is done ~one denoise layer after the prefix pass.
-                main = torch.cuda.current_stream()
-                side = self.__dict__.get("_side") or self.__dict__.setdefault("_side", torch.cuda.Stream())
-                st = {}
-
-                def kv_ready(l):
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ev)
-                        if l == 0:
-                            st["xs"], st["sq"] = first_rows()
-                            st["parts"] = 1
-                        transpose_v(l, 1)
-                        st["xs"], st["sq"], st["parts"] = self._expert_layer_folded(l, st["xs"], st["sq"], st["parts"], 0, rows0, folded)
-
-                self._prefix_pass(images, img_masks, lang_tokens, lang_masks, kv_ready=kv_ready)
-                main.wait_stream(side)
-                last = st["xs"]
-                last.record_stream(main)
-                first_step = 1
-            else:
-                self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
-                transpose_v(0, self.L)
-                xs, sq = first_rows()
-                last, first_step = None, 0
-            for step in range(first_step, n + 1):
+            # (Round 5, measured and removed: the first Euler step's chain on a second stream behind the prefix pass — layer l of step 0
+            # needs only layer l's K / V rows — is bit-identical and 0.6 ms SLOWER, 16.6 against 15.95 ms p50: a forked hipGraph replays
+            # slower than a linear one, as round 2 found for a much smaller branch.)
+            self._prefix_pass(images, img_masks, lang_tokens, lang_masks)
+            self._rope_cs = ops.rope_table(self.pos_suffix, self._inv_freq)
+            # prefix value rows of every layer -> transposed cache, one launch
+            ops.transpose_strided(self.v_all, self.vt_all, R=P, C=HD, src_ld=HD, dst_ld=S_ld, batch=self.L * B, src_bs=S_ld * HD,
+                                  dst_bs=HD * S_ld)
+            xs = torch.empty((M, De), dtype=BF16, device=self.dev)
+            sq = torch.empty((1, M), dtype=F32, device=self.dev)
+            ops.denoise_glue(x2, w_in=win, b_in=bin_, xs_next=xs, rowsq_next=sq)
+            last = None
+            for step in range(n + 1):
                 if step > 0:  # the seam behind step - 1 (and in front of `step`, if there is one)
                     more = step < n
                     xs = torch.empty((M, De), dtype=BF16, device=self.dev) if more else None

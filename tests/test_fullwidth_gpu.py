@@ -281,15 +281,8 @@ def test_fullwidth_production_denoise_stack_agrees_with_the_generic_path(fw):
             InferenceEngine.force_generic = False
         print(f"chunk: production stack vs generic per-layer path: rel-L2 {rel(ref, generic):.3e}")
         assert rel(ref, generic) < 3e-3, rel(ref, generic)
-        # the first Euler step on a second stream behind the prefix pass (default) moves launches, not arithmetic: bit-identical to
-        # the one-stream order; likewise the prefix attention as four key ranges + merge against GEMM + softmax + GEMM within round-off
-        assert eng.overlap_step0 and eng.key_split
-        InferenceEngine.overlap_step0 = False
-        try:
-            m.invalidate_inference_engine()
-            assert torch.equal(m.sample_actions(d, gobs, noise=noise, num_steps=10), ref)
-        finally:
-            InferenceEngine.overlap_step0 = True
+        # the prefix attention as four key ranges + merge (default) against logits GEMM + softmax + P V GEMM: within round-off
+        assert eng.key_split
         InferenceEngine.key_split = False
         try:
             m.invalidate_inference_engine()
