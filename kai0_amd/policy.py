@@ -41,11 +41,24 @@ def _map_leaves(fn, tree):
 class Policy(BasePolicy):
     def __init__(self, model, *, transforms: Sequence = (), output_transforms: Sequence = (),
                  sample_kwargs: dict[str, Any] | None = None, metadata: dict[str, Any] | None = None,
-                 pytorch_device: str = "cuda:0", is_pytorch: bool = True, rng=None):  # fmt: skip
+                 pytorch_device: str = "cuda:0", is_pytorch: bool = True, rng=None, device_resize: bool = True):  # fmt: skip
         if not is_pytorch:
             raise ValueError("kai0_amd.policy.Policy serves the torch-protocol model only (JAX checkpoints: convert first)")
         self._model = model.to(pytorch_device)
         self._model.eval()
+        # Round 5: the camera frames' resize (transforms.ResizeImages -> Pillow, ~1 ms per 480 x 640 frame on the host: 16 % of a
+        # request's wall time) moves behind the host-to-device copy when the model sits on a GPU: the raw uint8 frames cross PCIe and
+        # kai0_amd.device_resize resamples them with Pillow's own fixed-point arithmetic (bit-identical).  Only when nothing after
+        # ResizeImages in the stack looks at the images (the pi0.5 stack: TokenizePrompt, PadStatesAndActions).
+        transforms = list(transforms)
+        self._device_resize = None
+        image_blind = (_transforms.TokenizePrompt, _transforms.PadStatesAndActions, _transforms.InjectDefaultPrompt)
+        if device_resize == "force" or (device_resize and torch.device(pytorch_device).type == "cuda"):  # ("force": tests on the CPU)
+            for i, t in enumerate(transforms):
+                if isinstance(t, _transforms.ResizeImages) and all(isinstance(u, image_blind) for u in transforms[i + 1 :]):
+                    self._device_resize = t
+                    transforms = transforms[:i] + transforms[i + 1 :]
+                    break
         self._input_transform = _transforms.compose(transforms)
         self._output_transform = _transforms.compose(output_transforms)
         self._sample_kwargs = sample_kwargs or {}
@@ -57,7 +70,14 @@ class Policy(BasePolicy):
         dev = self._pytorch_device
         inputs = _map_leaves(lambda x: x, obs)  # shallow structural copy: transforms may rebind entries
         inputs = self._input_transform(inputs)
+        rs = self._device_resize
+        if rs is not None and not all(isinstance(v, np.ndarray) and v.dtype == np.uint8 for v in inputs["image"].values()):
+            inputs, rs = rs(inputs), None  # float frames: the host path, as before
         inputs = _map_leaves(lambda x: torch.from_numpy(np.array(x)).to(dev)[None, ...], inputs)
+        if rs is not None:
+            from .device_resize import resize_with_pad_u8
+
+            inputs["image"] = {k: resize_with_pad_u8(v, rs.height, rs.width) for k, v in inputs["image"].items()}
         kwargs = dict(self._sample_kwargs)
         if noise is not None:
             n = torch.from_numpy(noise).to(dev)
@@ -86,7 +106,7 @@ def create_policy(model, *, norm_stats: Mapping | None, tokenizer, action_dim: i
                   discrete_state_input: bool = True, image_size: int = 224, robot_inputs: Sequence = (),
                   robot_outputs: Sequence = (), repack_transforms: _transforms.Group | None = None,
                   default_prompt: str | None = None, sample_kwargs: dict | None = None, metadata: dict | None = None,
-                  pytorch_device: str = "cuda:0") -> Policy:  # fmt: skip
+                  pytorch_device: str = "cuda:0", device_resize=True) -> Policy:  # fmt: skip
     """The transform stack of `create_trained_policy` (policy_config.py:75-94) with the pi0.5 model transforms of
     `ModelTransformFactory` (training/config.py:129-141), assembled from explicit pieces instead of a TrainConfig:
       inputs : repack -> default prompt -> robot inputs -> Normalize -> [default prompt, ResizeImages, TokenizePrompt,
@@ -101,7 +121,7 @@ def create_policy(model, *, norm_stats: Mapping | None, tokenizer, action_dim: i
                     _transforms.TokenizePrompt(tokenizer, discrete_state_input=discrete_state_input),
                     _transforms.PadStatesAndActions(action_dim)],
         output_transforms=[_transforms.Unnormalize(norm_stats, use_quantiles=use_quantile_norm), *robot_outputs, *repack.outputs],
-        sample_kwargs=sample_kwargs, metadata=metadata, pytorch_device=pytorch_device)  # fmt: skip
+        sample_kwargs=sample_kwargs, metadata=metadata, pytorch_device=pytorch_device, device_resize=device_resize)  # fmt: skip
 
 
 def create_trained_policy(train_config, checkpoint_dir, *, repack_transforms: _transforms.Group | None = None,

@@ -260,3 +260,31 @@ def test_policy_infer_flow_against_reference_output():
     assert np.array_equal(res["actions"], G["pol.noise.actions"])
     assert res["policy_timing"]["infer_ms"] >= 0 and pol.metadata == {"robot": "agilex"}
     assert "prompt" in obs and obs["state"][3] == 4.0  # the caller's dict is not modified
+    # round 5: the frames' resize behind the host-to-device copy (kai0_amd.device_resize; on by default when the model sits on a GPU,
+    # forced here): the reference's output, bit for bit
+    pol2 = policy.create_policy(_FakeModel(), norm_stats=stats, tokenizer=tok, action_dim=32, use_quantile_norm=True, image_size=28,
+                                robot_inputs=[agilex_policy.AgilexInputs(action_dim=32, model_type="pi05")],
+                                robot_outputs=[agilex_policy.AgilexOutputs()], sample_kwargs={"num_steps": 10},
+                                metadata={"robot": "agilex"}, pytorch_device="cpu", device_resize="force")  # fmt: skip
+    assert pol2._device_resize is not None and pol._device_resize is None
+    assert np.array_equal(pol2.infer({**obs, "images": dict(cams)})["actions"], G["pol.plain.actions"])
+    assert np.array_equal(pol2.infer({**obs, "images": dict(cams)}, noise=G["pol.noise"])["actions"], G["pol.noise.actions"])
+
+
+@pytest.mark.parametrize("h0,w0,H,W", [(480, 640, 224, 224), (224, 224, 224, 224), (100, 120, 224, 224), (720, 1280, 224, 224),
+                                       (481, 643, 224, 224), (300, 200, 224, 224), (37, 53, 64, 48), (50, 1000, 224, 224)])
+def test_device_resize_is_pillow_bit_for_bit(h0, w0, H, W):
+    """kai0_amd.device_resize (torch integer arithmetic, any device) against image_tools.resize_with_pad (Pillow BILINEAR, what the
+    reference's serve path runs, openpi_client/image_tools.py:7-58): noise, saturated and ramp frames, down- and upscaling, odd sizes,
+    a batch with leading dimensions."""
+    from kai0_amd import device_resize
+
+    rng = np.random.default_rng(h0 * 1000 + w0)
+    frames = [rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8), np.full((h0, w0, 3), 255, np.uint8),
+              (np.indices((h0, w0)).sum(0) % 256).astype(np.uint8)[..., None].repeat(3, -1)]
+    for f in frames:
+        assert np.array_equal(device_resize.resize_with_pad_u8(torch.from_numpy(f), H, W).numpy(), image_tools.resize_with_pad(f, H, W))
+    batch = np.stack(frames)[None]
+    assert np.array_equal(device_resize.resize_with_pad_u8(torch.from_numpy(batch), H, W).numpy(), image_tools.resize_with_pad(batch, H, W))
+    with pytest.raises(TypeError):
+        device_resize.resize_with_pad_u8(torch.zeros(4, 4, 3), 2, 2)
