@@ -56,7 +56,7 @@ def run(trim: bool):
 
 
 res = {"requests": n_req, **run(False), "trimmed_prompt": run(True),
-       "note": "three 480x640 uint8 cameras -> resize_with_pad 224 (PIL) -> tokenise -> H2D -> sample_actions (graph) -> D2H -> unnormalise; "
+       "note": "three 480x640 uint8 cameras -> tokenise -> H2D (raw frames) -> resize_with_pad 224 on the device (kai0_amd.device_resize, Pillow-bit-identical) -> sample_actions (graph) -> D2H -> unnormalise; "
                "top level: all max_token_len prompt slots computed; trimmed_prompt: the serve default (slots the prompt does not fill dropped)"}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "policy_latency.json"), "w"), indent=1)
