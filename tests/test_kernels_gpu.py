@@ -1453,3 +1453,18 @@ def test_rope_two_tensors_in_one_launch(ops):
     q2, k2 = q.clone(), k.clone()
     ops.rope2_(q2, H, k2, 1, pos, inv, B, S, S_ld, 0, HD)
     assert torch.equal(q1, q2) and torch.equal(k1, k2) and not torch.equal(q1, q)
+
+
+def test_device_resize_on_the_gpu_is_pillow_bit_for_bit():
+    """kai0_amd.device_resize on cuda:0 (the serve path's default when the model sits on a GPU) against Pillow on the host: three
+    480 x 640 camera frames -> 224 x 224 with padding, and an upscale."""
+    import numpy as np
+
+    from kai0_amd import device_resize, image_tools
+
+    rng = np.random.default_rng(7)
+    for shape, (H, W) in (((3, 480, 640, 3), (224, 224)), ((1, 100, 120, 3), (224, 224)), ((2, 720, 1280, 3), (224, 224))):
+        frames = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = device_resize.resize_with_pad_u8(torch.from_numpy(frames).to(dev()), H, W)
+        assert got.is_cuda and got.dtype == torch.uint8
+        assert np.array_equal(got.cpu().numpy(), image_tools.resize_with_pad(frames, H, W))
