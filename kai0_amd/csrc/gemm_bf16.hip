@@ -1145,6 +1145,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
 constexpr int PS_SLOTS = 1024;
 __device__ unsigned int g_ps_ctr[PS_SLOTS][16];
 
+// diagnostics (KAI0_HIPCC_FLAGS=-DKAI0_PS_TRACE, tools/probes/persistent_phases.py): per block of the persistent kernel, 100 MHz ticks
+// spent in  0 tile start  1 K loop  2 hand-over issue + epilogue passes  3 ticket / drain / barriers  and 4 = tiles run
+#ifdef KAI0_PS_TRACE
+__device__ long long g_ps_trace[256][8];
+#define PS_STAMP(i)                                              \
+    do {                                                         \
+        const long long n_ = __builtin_amdgcn_s_memrealtime();   \
+        t_acc[i] += n_ - t_prev;                                 \
+        t_prev = n_;                                             \
+    } while (0)
+#else
+#define PS_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmArgs p, unsigned int* __restrict__ ctr) {
     constexpr int TBM = 256, TBN = 256, A_TILE = TBM * BK * 2, STAGE = 2 * A_TILE, GROUP = 4, MT = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1259,6 +1273,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         if (grp == 1) lds_barrier();  // stagger group 1 by one slot
     }
     const int64_t cz = 0, rz = 0, vz = 0;
+#ifdef KAI0_PS_TRACE
+    long long t_acc[5] = {0, 0, 0, 0, 0};
+    long long t_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     while (cur >= 0) {
         f32x4 acc[MT][4];
 #pragma unroll
@@ -1293,6 +1311,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        PS_STAMP(0);
         for (int t = 0; t < nk; ++t) {
             const char* ta = smem + (t & 1) * STAGE;
             const char* tb = ta + A_TILE;
@@ -1329,6 +1348,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         if (grp == 0) lds_barrier();                      // re-align the two groups
         lds_barrier();
 
+        PS_STAMP(1);
         // ---- hand-over: ticket for the tile after next, next tile's first half-tiles, THEN this tile's epilogue ------------------
         const int m0c = m0, n0c = n0;
         int nn = -1;
@@ -1473,6 +1493,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
                 }
             }
         }
+        PS_STAMP(2);
         // ---- next tile ------------------------------------------------------------------------------------------------------------
         __builtin_amdgcn_wave_barrier();
         if (tid == 0) mbox[0] = nxt >= 0 ? resolve(raw) : -1;
@@ -1483,7 +1504,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         nxt = nn;
         lds_barrier();  // everyone has read the mailbox before wave 0's slab is written again
         if (cur >= 0 && grp == 1) lds_barrier();  // stagger group 1 by one slot
+        PS_STAMP(3);
+#ifdef KAI0_PS_TRACE
+        t_acc[4] += 1;
+#endif
     }
+#ifdef KAI0_PS_TRACE
+    if (tid == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 5; ++i) g_ps_trace[blockIdx.x][i] = t_acc[i];
+#endif
     // ---- leave: the last block zeroes the launch's counters (the slot is then reusable by a later launch / a graph replay) ---------
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1670,6 +1699,12 @@ KAI0_API int kai0_gemm_set_cfg(int cfg) {
     g_gemm_cfg = cfg;
     return old;
 }
+
+#ifdef KAI0_PS_TRACE
+KAI0_API int kai0_debug_ps_trace(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ps_trace), sizeof(long long) * 256 * 8);
+}
+#endif
 
 KAI0_API int kai0_gemm_set_persist(int mode) {
     const int old = g_gemm_persist;
