@@ -167,6 +167,10 @@ int kai0_gemm_set_cfg(int cfg);
  * a fused GeGLU / GELU epilogue or K <= 2048 (default; env KAI0_GEMM_PERSIST), 2 = every eligible NT launch.  Results are bit-identical
  * to the one-block-per-tile launches.  Returns the previous mode. */
 int kai0_gemm_set_persist(int mode);
+/* Diagnostics: 0 sends the 256 x 256 launches whose epilogue is a store with little else (act 0 / 1, optional bias / residual / column
+ * routing; no gate, accumulate, f32 output, scale or row map) through the general per-row epilogue instead of their fast path (default 1).
+ * Both produce the same bits (tests/test_kernels_gpu.py).  Returns the previous setting.  Not thread-safe. */
+int kai0_gemm_set_simple_epilogue(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Few-row weight-streaming GEMM for the denoise loop (B*action_horizon <= a few 64-row tiles):

@@ -121,6 +121,7 @@ _PROTOS: dict[str, list] = {
     "kai0_gemm_desc_size": [],
     "kai0_gemm_set_cfg": [c_i],
     "kai0_gemm_set_persist": [c_i],
+    "kai0_gemm_set_simple_epilogue": [c_i],
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "kai0_attn_fwd": [C.POINTER(AttnDesc), c_p],

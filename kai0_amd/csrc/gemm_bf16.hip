@@ -74,6 +74,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
     int nt_c;    // C stored non-temporally (kai0hip.h c_nontemporal: weight gradients, read again only by the optimizer)
+    int simple_epi;  // the store-with-little-else fast epilogue may be used (kai0_gemm_set_simple_epilogue, tests)
     int nt_pre;  // pre-activation outputs (pre_out / pre_out2 of act 1 and 6: read again only by the backward) stored non-temporally
     const float* rowvec;   // act 4: per-row f32 vector D (softmax backward), index z1*rv_s1 + z2*rv_s2 + row*rv_ld
     int64_t rv_s1, rv_s2, rv_ld;
@@ -832,6 +833,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     // plain epilogues that read operands (bias and / or residual; optional GELU): see epi_half
     const bool plain_fast = p.act <= 1 && p.split_k == 1 && (p.bias != nullptr || p.residual != nullptr) && p.gate == nullptr &&
                             !p.accumulate && !p.out_f32 && p.nseg == 0 && (N_ALIGNED8(p.N));
+    // 256x256 configurations: the store-with-little-else epilogues (act 0 / 1, optional bias, optional residual, optional column routing;
+    // no gate / accumulate / f32 output / scale / row map) without the general path's per-row checks of everything else — measured in
+    // the persistent kernel: 9.7 -> 4.6 us per tile for a plain store (profiles/r05_gemm_persistent_phases.txt).  Same order and rounding
+    // points as epilogue8; kai0_gemm_set_simple_epilogue(0) sends these launches through the general path (tests).
+    const bool simple_fast = MT == 8 && p.simple_epi && p.act <= 1 && p.split_k == 1 && p.gate == nullptr && !p.accumulate && !p.out_f32 &&
+                             p.scale == 1.0f && p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         if constexpr (MT == 4 && WM == 2 && WN == 2 && A_KC && B_KC) if (p.act == 7) {
@@ -1088,6 +1095,99 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
                 *reinterpret_cast<bf16x8*>(cb + o) = ov;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+        if constexpr (MT == 8) if (simple_fast) {
+            // (every argument used inside the unrolled loops is read ONCE here: hipcc reads the argument block from constant memory only
+            // while it has fewer than 300 uses in a kernel, beyond that it copies the whole block to scratch)
+            const bool has_bias = p.bias != nullptr, has_res = p.residual != nullptr, gelu = p.act == 1;
+            const int M_ = p.M, nt_pre_ = p.nt_pre, nt_c_ = p.nt_c;
+            const bf16_t* res_ = p.residual;
+            bf16_t* pre_ = p.pre_out;
+            const int64_t ldr_ = p.ldr, ldc_ = p.ldc;
+            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (has_bias && col_ok) {  // a lane's 8 columns are the same for all of its rows
+                if (p.bias_f32) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.bias) + ccol);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.bias) + ccol + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                } else {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bias) + ccol);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = bf2f(b[e]);
+                }
+            }
+            // destination of the lane's 8 columns (column routing resolved once: the columns do not change with the row)
+            bf16_t* cl = reinterpret_cast<bf16_t*>(p.C) + cz + ccol;
+            int64_t ldl = p.ldc;
+            if (p.nseg > 0) {  // (constant indices only: a run-time index would put the whole argument block into scratch)
+                cl = p.seg_dst[0] + (ccol - p.seg_begin[0]);
+                ldl = p.seg_ld[0];
+                if (p.nseg > 1 && ccol >= p.seg_begin[1]) {
+                    cl = p.seg_dst[1] + (ccol - p.seg_begin[1]);
+                    ldl = p.seg_ld[1];
+                }
+                if (p.nseg > 2 && ccol >= p.seg_begin[2]) {
+                    cl = p.seg_dst[2] + (ccol - p.seg_begin[2]);
+                    ldl = p.seg_ld[2];
+                }
+            }
+            const int rbase = row_base(h) + (lane >> 3);
+            auto res_row = [&](int it) -> bf16x8 {
+                const int row = rbase + it * 8;
+                return (has_res && row < M_ && col_ok) ? *reinterpret_cast<const bf16x8*>(res_ + rz + (int64_t)row * ldr_ + ccol) : bf16x8{};
+            };
+            bf16x8 rnext = res_row(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + it * 8;
+                const float* sp = slab + (it * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const bf16x8 rv = rnext;
+                if (it + 1 < 8) rnext = res_row(it + 1);  // (one row ahead: its latency hides behind this row's arithmetic)
+                if (row >= M_ || !col_ok) continue;
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]);
+                if (gelu) {
+                    if (pre_ != nullptr) {
+                        bf16x8 pv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
+                        store_pre8(pre_ + cz + (int64_t)row * ldc_ + ccol, pv, nt_pre_);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 a = gelu_tanh2(f32x2{v[e], v[e + 1]});
+                        v[e] = rbf(a[0]);
+                        v[e + 1] = rbf(a[1]);
+                    }
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rv[e]));
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+                store_pre8(cl + (int64_t)row * ldl, ov, nt_c_);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -1362,7 +1462,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         const bool col_ok = ccol < ((p.N + 7) & ~7);
         const bool fused_fast = p.act >= 2 && p.act <= 5 && p.bias == nullptr && p.gate == nullptr && p.residual == nullptr && !p.accumulate &&
                                 !p.out_f32 && p.nseg == 0 && (p.act == 4 || p.scale == 1.0f) && (p.act != 3 || p.pre_out != nullptr);
-        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab
+        const bool simple_fast = p.simple_epi && p.act <= 1 && p.gate == nullptr && !p.accumulate && !p.out_f32 && p.scale == 1.0f &&
+                                 p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
+        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab
             __builtin_amdgcn_wave_barrier();
             // (static indexing of acc: callers pass compile-time ti through the unrolled loops below)
 #pragma unroll
@@ -1475,6 +1577,89 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
                         }
                         *reinterpret_cast<bf16x8*>(cb + o) = ov;
                     }
+                }
+            }
+        } else if (simple_fast) {
+            // store-with-little-else (act 0 / 1, optional bias / residual / column routing): see gemm_bf16_kernel's simple_fast
+            const bool has_bias = p.bias != nullptr, has_res = p.residual != nullptr, gelu = p.act == 1;
+            const int M_ = p.M, nt_pre_ = p.nt_pre, nt_c_ = p.nt_c;  // (read once: see gemm_bf16_kernel)
+            const bf16_t* res_ = p.residual;
+            bf16_t* pre_ = p.pre_out;
+            const int64_t ldr_ = p.ldr, ldc_ = p.ldc;
+            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (has_bias && col_ok) {
+                if (p.bias_f32) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.bias) + ccol);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.bias) + ccol + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                } else {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bias) + ccol);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = bf2f(b[e]);
+                }
+            }
+            bf16_t* cl = reinterpret_cast<bf16_t*>(p.C) + ccol;
+            int64_t ldl = p.ldc;
+            if (p.nseg > 0) {  // (constant indices only: a run-time index would put the whole argument block into scratch)
+                cl = p.seg_dst[0] + (ccol - p.seg_begin[0]);
+                ldl = p.seg_ld[0];
+                if (p.nseg > 1 && ccol >= p.seg_begin[1]) {
+                    cl = p.seg_dst[1] + (ccol - p.seg_begin[1]);
+                    ldl = p.seg_ld[1];
+                }
+                if (p.nseg > 2 && ccol >= p.seg_begin[2]) {
+                    cl = p.seg_dst[2] + (ccol - p.seg_begin[2]);
+                    ldl = p.seg_ld[2];
+                }
+            }
+            const int rbase = m0c + wm * 128 + (lane >> 3);
+            auto res_row = [&](int k) -> bf16x8 {  // k = 16-row pass * 2 + 8-row step
+                const int row = rbase + k * 8;
+                return (has_res && row < M_ && col_ok) ? *reinterpret_cast<const bf16x8*>(res_ + (int64_t)row * ldr_ + ccol) : bf16x8{};
+            };
+            bf16x8 rnext = res_row(0);
+#pragma unroll
+            for (int ti = 0; ti < MT; ++ti) {
+                to_slab(ti);
+#pragma unroll
+                for (int it2 = 0; it2 < 2; ++it2) {
+                    const int k = ti * 2 + it2;
+                    const int row = rbase + k * 8;
+                    const float* sp = slab + (it2 * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                    const bf16x8 rv = rnext;
+                    if (k + 1 < 2 * MT) rnext = res_row(k + 1);
+                    if (row >= M_ || !col_ok) continue;
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (has_bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]);
+                    if (gelu) {
+                        if (pre_ != nullptr) {
+                            bf16x8 pv;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) pv[e] = f2bf(v[e]);
+                            store_pre8(pre_ + (int64_t)row * ldc_ + ccol, pv, nt_pre_);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 a = gelu_tanh2(f32x2{v[e], v[e + 1]});
+                            v[e] = rbf(a[0]);
+                            v[e + 1] = rbf(a[1]);
+                        }
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rv[e]));
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = f2bf(v[e]);
+                    store_pre8(cl + (int64_t)row * ldl, ov, nt_c_);
                 }
             }
         } else {
@@ -1690,6 +1875,7 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
 }
 
 int g_gemm_cfg = 0;  // kai0_gemm_set_cfg (tools / tests): no environment switch
+int g_gemm_simple_epi = 1;  // kai0_gemm_set_simple_epilogue
 int g_gemm_persist = [] { const char* e = getenv("KAI0_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
 
 }  // namespace
@@ -1705,6 +1891,12 @@ KAI0_API int kai0_debug_ps_trace(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ps_trace), sizeof(long long) * 256 * 8);
 }
 #endif
+
+KAI0_API int kai0_gemm_set_simple_epilogue(int on) {
+    const int old = g_gemm_simple_epi;
+    g_gemm_simple_epi = on;
+    return old;
+}
 
 KAI0_API int kai0_gemm_set_persist(int mode) {
     const int old = g_gemm_persist;
@@ -1821,6 +2013,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // caller sets c_nontemporal (weight gradients)
     p.nt_pre = 1;
     p.nt_c = d->c_nontemporal != 0;
+    p.simple_epi = g_gemm_simple_epi;
     p.rowvec = d->rowvec; p.rv_s1 = d->rv_s1; p.rv_s2 = d->rv_s2; p.rv_ld = d->rv_ld;
     p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {

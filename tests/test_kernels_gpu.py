@@ -1126,6 +1126,68 @@ def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
         assert rel_err(got.view(n, S, NH, HD).transpose(1, 2), ref) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("persist", [0, 2])
+@pytest.mark.parametrize("case", ["plain", "bias", "bias_f32", "bias_res", "res", "gelu_pre", "gelu_res", "routed", "ragged_rows", "batched", "tn"])
+def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persist):
+    """256 x 256 launches whose epilogue is a store with little else (act 0 / 1, bias, residual, column routing) take a fast path that
+    skips the general epilogue's per-row checks; kai0_gemm_set_simple_epilogue(0) sends them through the general path: same bits in
+    every output, in the one-block-per-tile kernels (persist 0) and in the persistent kernel (persist 2), with ragged rows, batch
+    entries (their C / residual strides) and the transpose-read layout of the weight gradients."""
+    from kai0_amd import _lib
+
+    lib = _lib.load()
+    M, N, K = (4000, 4096, 320) if case == "ragged_rows" else (4096, 4096, 320)
+    if persist == 2:
+        N = 8192  # (512 tiles: the persistent kernel's minimum; batched / transpose-read launches never take it)
+    kw, nout, batch = {}, 1, 1
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    lay = dict(lda=K, ldb=K)
+    if case == "bias":
+        kw = dict(bias=rnd(N, seed=3))
+    elif case == "bias_f32":
+        kw = dict(bias=rnd(N, seed=3).float())
+    elif case in ("bias_res", "ragged_rows"):
+        kw = dict(bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N)
+    elif case == "res":
+        kw = dict(residual=rnd(M, N, seed=4), ldr=N)
+    elif case == "gelu_pre":
+        kw, nout = dict(bias=rnd(N, seed=3), act=1), 2
+    elif case == "gelu_res":
+        kw, nout = dict(act=1, residual=rnd(M, N, seed=4), ldr=N), 2
+    elif case == "batched":
+        batch = 2
+        A, W = rnd(batch * M, K, seed=1), rnd(batch * N, K, seed=2, scale=0.05)
+        kw = dict(batch=batch, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0), sR=(M * N, 0), bias=rnd(N, seed=3), residual=rnd(batch * M, N, seed=4), ldr=N)
+    elif case == "tn":  # C[M][N] = A[K][M]^T B[K][N]
+        A, W = rnd(K, M, seed=1), rnd(K, N, seed=2, scale=0.05)
+        lay = dict(a_kc=False, b_kc=False, lda=M, ldb=N)
+    res = {}
+    try:
+        lib.kai0_gemm_set_persist(persist)
+        for simple in (0, 1):
+            lib.kai0_gemm_set_simple_epilogue(simple)
+            outs = [torch.full((batch * M, N), 3.0, dtype=BF16, device=dev()) for _ in range(nout)]
+            k2 = dict(kw)
+            if nout >= 2:
+                k2["pre_out"] = outs[1]
+            if case == "routed":  # columns [0, N/2) | [N/2, 3N/4) | [3N/4, N) to three destinations with their own row strides
+                dst = [torch.full((M, w), 3.0, dtype=BF16, device=dev()) for w in (N // 2, N // 4, N // 4)]
+                k2["segs"] = [(dst[0], N // 2, 0), (dst[1], N // 4, N // 2), (dst[2], N // 4, 3 * N // 4)]
+                outs = outs + dst
+            ops.gemm(A, W, outs[0], M=M, N=N, K=K, ldc=N, **lay, **k2)
+            torch.cuda.synchronize()
+            res[simple] = outs
+    finally:
+        lib.kai0_gemm_set_simple_epilogue(1)
+        lib.kai0_gemm_set_persist(1)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    if case == "plain":
+        assert rel_err(res[1][0], A.float() @ W.float().t()) < 5e-3
+    if case == "routed":
+        assert not torch.equal(res[1][1], torch.full_like(res[1][1], 3.0))  # the routed destinations were written
+
+
 @pytest.mark.parametrize("case", ["plain", "bias_res", "gelu_pre", "geglu_pair", "geglu_fwd", "geglu_bwd", "gelu_bwd", "ragged"])
 def test_persistent_gemm_is_bit_identical_to_one_block_per_tile(ops, case):
     """kai0_gemm_set_persist(2): the persistent NT kernel (dynamic per-XCD tile queue, next tile staged before the epilogue, 16-row
