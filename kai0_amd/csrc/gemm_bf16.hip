@@ -833,12 +833,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     // plain epilogues that read operands (bias and / or residual; optional GELU): see epi_half
     const bool plain_fast = p.act <= 1 && p.split_k == 1 && (p.bias != nullptr || p.residual != nullptr) && p.gate == nullptr &&
                             !p.accumulate && !p.out_f32 && p.nseg == 0 && (N_ALIGNED8(p.N));
-    // 256x256 configurations: the store-with-little-else epilogues (act 0 / 1, optional bias, optional residual, optional column routing;
-    // no gate / accumulate / f32 output / scale / row map) without the general path's per-row checks of everything else — measured in
+    // 256x256 configurations: the store-with-little-else epilogues (act 0 / 1, optional bias, optional residual, optional column routing,
+    // optional accumulation into the bf16 destination; no gate / f32 output / scale / row map) without the general path's per-row checks of everything else — measured in
     // the persistent kernel: 9.7 -> 4.6 us per tile for a plain store (profiles/r05_gemm_persistent_phases.txt).  Same order and rounding
     // points as epilogue8; kai0_gemm_set_simple_epilogue(0) sends these launches through the general path (tests).
-    const bool simple_fast = MT == 8 && p.simple_epi && p.act <= 1 && p.split_k == 1 && p.gate == nullptr && !p.accumulate && !p.out_f32 &&
-                             p.scale == 1.0f && p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
+    const bool simple_fast = MT == 8 && p.simple_epi && p.act <= 1 && p.split_k == 1 && p.gate == nullptr && !p.out_f32 && p.scale == 1.0f &&
+                             p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         if constexpr (MT == 4 && WM == 2 && WN == 2 && A_KC && B_KC) if (p.act == 7) {
@@ -1141,7 +1141,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 const int row = rbase + it * 8;
                 return (has_res && row < M_ && col_ok) ? *reinterpret_cast<const bf16x8*>(res_ + rz + (int64_t)row * ldr_ + ccol) : bf16x8{};
             };
-            bf16x8 rnext = res_row(0);
+            const bool accum = p.accumulate != 0;
+            auto old_row = [&](int it) -> bf16x8 {  // accumulate: what the destination holds
+                const int row = rbase + it * 8;
+                return (accum && row < M_ && col_ok) ? *reinterpret_cast<const bf16x8*>(cl + (int64_t)row * ldl) : bf16x8{};
+            };
+            bf16x8 rnext = res_row(0), onext = old_row(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1156,8 +1161,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 const float* sp = slab + (it * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                const bf16x8 rv = rnext;
-                if (it + 1 < 8) rnext = res_row(it + 1);  // (one row ahead: its latency hides behind this row's arithmetic)
+                const bf16x8 rv = rnext, ov0 = onext;
+                if (it + 1 < 8) {  // (one row ahead: the latency hides behind this row's arithmetic)
+                    rnext = res_row(it + 1);
+                    onext = old_row(it + 1);
+                }
                 if (row >= M_ || !col_ok) continue;
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if (has_bias) {
@@ -1183,6 +1191,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                 if (has_res) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rv[e]));
+                }
+                if (accum) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf2f(ov0[e]);
                 }
                 bf16x8 ov;
 #pragma unroll
@@ -1462,8 +1474,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         const bool col_ok = ccol < ((p.N + 7) & ~7);
         const bool fused_fast = p.act >= 2 && p.act <= 5 && p.bias == nullptr && p.gate == nullptr && p.residual == nullptr && !p.accumulate &&
                                 !p.out_f32 && p.nseg == 0 && (p.act == 4 || p.scale == 1.0f) && (p.act != 3 || p.pre_out != nullptr);
-        const bool simple_fast = p.simple_epi && p.act <= 1 && p.gate == nullptr && !p.accumulate && !p.out_f32 && p.scale == 1.0f &&
-                                 p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
+        const bool simple_fast = p.simple_epi && p.act <= 1 && p.gate == nullptr && !p.out_f32 && p.scale == 1.0f && p.cmap.rpb == 0 &&
+                                 (N_ALIGNED8(p.N));
         auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab
             __builtin_amdgcn_wave_barrier();
             // (static indexing of acc: callers pass compile-time ti through the unrolled loops below)
@@ -1618,7 +1630,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
                 const int row = rbase + k * 8;
                 return (has_res && row < M_ && col_ok) ? *reinterpret_cast<const bf16x8*>(res_ + (int64_t)row * ldr_ + ccol) : bf16x8{};
             };
-            bf16x8 rnext = res_row(0);
+            const bool accum = p.accumulate != 0;
+            auto old_row = [&](int k) -> bf16x8 {
+                const int row = rbase + k * 8;
+                return (accum && row < M_ && col_ok) ? *reinterpret_cast<const bf16x8*>(cl + (int64_t)row * ldl) : bf16x8{};
+            };
+            bf16x8 rnext = res_row(0), onext = old_row(0);
 #pragma unroll
             for (int ti = 0; ti < MT; ++ti) {
                 to_slab(ti);
@@ -1628,8 +1645,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
                     const int row = rbase + k * 8;
                     const float* sp = slab + (it2 * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                    const bf16x8 rv = rnext;
-                    if (k + 1 < 2 * MT) rnext = res_row(k + 1);
+                    const bf16x8 rv = rnext, ov0 = onext;
+                    if (k + 1 < 2 * MT) {
+                        rnext = res_row(k + 1);
+                        onext = old_row(k + 1);
+                    }
                     if (row >= M_ || !col_ok) continue;
                     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     if (has_bias) {
@@ -1655,6 +1675,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
                     if (has_res) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bf2f(rv[e]));
+                    }
+                    if (accum) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf2f(ov0[e]);
                     }
                     bf16x8 ov;
 #pragma unroll

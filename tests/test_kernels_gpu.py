@@ -1127,10 +1127,10 @@ def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
 
 
 @pytest.mark.parametrize("persist", [0, 2])
-@pytest.mark.parametrize("case", ["plain", "bias", "bias_f32", "bias_res", "res", "gelu_pre", "gelu_res", "routed", "ragged_rows", "batched", "tn"])
+@pytest.mark.parametrize("case", ["plain", "bias", "bias_f32", "bias_res", "res", "gelu_pre", "gelu_res", "routed", "ragged_rows", "batched", "tn", "accum", "accum_res"])
 def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persist):
     """256 x 256 launches whose epilogue is a store with little else (act 0 / 1, bias, residual, column routing) take a fast path that
-    skips the general epilogue's per-row checks; kai0_gemm_set_simple_epilogue(0) sends them through the general path: same bits in
+    skips the general epilogue's per-row checks (also when it accumulates into the destination); kai0_gemm_set_simple_epilogue(0) sends them through the general path: same bits in
     every output, in the one-block-per-tile kernels (persist 0) and in the persistent kernel (persist 2), with ragged rows, batch
     entries (their C / residual strides) and the transpose-read layout of the weight gradients."""
     from kai0_amd import _lib
@@ -1161,6 +1161,10 @@ def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persis
     elif case == "tn":  # C[M][N] = A[K][M]^T B[K][N]
         A, W = rnd(K, M, seed=1), rnd(K, N, seed=2, scale=0.05)
         lay = dict(a_kc=False, b_kc=False, lda=M, ldb=N)
+    elif case == "accum":  # C += A W^T (the destination's 3.0 fill is what it accumulates into)
+        kw = dict(accumulate=True)
+    elif case == "accum_res":
+        kw = dict(accumulate=True, bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N)
     res = {}
     try:
         lib.kai0_gemm_set_persist(persist)
