@@ -690,6 +690,8 @@ def main():
                 "step_frac_priced_on_tflop_per_sample": TRAIN_TFLOP_NEEDED_PER_SAMPLE,
                 "families": timer.families(B, timer_steps),
                 "targets": {"gemma_blocks_frac": 0.40, "vit_blocks_frac": 0.40},
+                "peak_note": "peak = the guide's dense bf16 figure at 2.4 GHz; under these launches the socket sits at its 1400 W cap with the "
+                             "shader clock at 1.8-2.1 GHz (profiles/r05_clock_power_under_gemm.txt, not re-measured by this run)",
             }
             if os.environ.get("KAI0_GEMM_BREAKDOWN"):
                 os.makedirs("gpurun_out", exist_ok=True)
