@@ -30,6 +30,7 @@ def case(name, M, N, K, act=0, bias=False, residual=False):
     if act in (2, 3, 5):
         kw = dict(act=act, aux1=rnd(M, N))
         if act == 3: kw["aux2"] = rnd(M, N)
+    if act == 1: kw = dict(act=1)
     if bias: kw["bias"] = rnd(N)
     if residual: kw.update(residual=rnd(M, N), ldr=N)
     res = {}
