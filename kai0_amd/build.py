@@ -40,12 +40,17 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
         results = list(pool.map(compile_one, srcs))
     objs = [o for o, _ in results]
-    if not force and OUT.exists() and not any(c for _, c in results) and all(OUT.stat().st_mtime >= o.stat().st_mtime for o in objs):
+    # which flag set the library on disk was linked from (a KAI0_HIPCC_FLAGS build leaves up-to-date objects of the DEFAULT build behind it:
+    # without this stamp the next default build would find nothing stale and keep the diagnostic library)
+    stamp = OUT.parent / "linked_with_flags.txt"
+    same_flags = stamp.exists() and stamp.read_text() == " ".join(extra)
+    if not force and OUT.exists() and same_flags and not any(c for _, c in results) and all(OUT.stat().st_mtime >= o.stat().st_mtime for o in objs):
         return OUT
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *map(str, objs), "-o", str(OUT)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    stamp.write_text(" ".join(extra))
     return OUT
 
 
