@@ -154,23 +154,27 @@ typedef struct kai0_gemm_desc {
     const void* rope_cos;
     const void* rope_sin;
     int32_t rope_half, rope_n_end;
+    /* A/B and test hooks, all 0 in production.  They are per CALL: the library keeps no process-wide mutable switches (SURVEY.md §8b
+     * "no globals beyond a per-device handle" — what remains static is per-device set-up: kernel LDS attributes, the CU count and
+     * the persistent kernel's self-cleaning counter slots).
+     *   tile_cfg          force a tile / schedule configuration: 0 = automatic; 1 / 2 = 128 x 128 with 2 / 4 stages; 3 = 128 x 128 on eight
+     *                     waves (4 stages); 4 = 256 x 256 plain loop; 5 = 256 x 256 two-buffer ping-pong for every layout
+     *   persist           persistent NT kernel (one resident block per CU drawing 256 x 256 tiles from an atomic, XCD-grouped ticket queue;
+     *                     the next tile's first half-tiles are staged before the current tile's epilogue; bit-identical to one block per
+     *                     tile): 0 = the library's rule (K-contiguous one-entry GEMMs of >= 2048 tiles with N >= 8192 or K >= 8192),
+     *                     1 = never, 2 = every eligible NT launch of >= 512 tiles
+     *   general_epilogue  1 sends the 256 x 256 launches whose epilogue is a store with little else (act 0 / 1, optional bias / residual /
+     *                     column routing; no gate, f32 output, scale or row map) through the general per-row epilogue instead of their
+     *                     fast path — same bits (tests/test_kernels_gpu.py)
+     *   small_w8          the 128 x 128 tile on eight waves (two per SIMD) instead of four: 0 = the library's rule (launches of at most
+     *                     one block per CU with K-contiguous operands and act 0 / 1), 1 = never, 2 = every eligible 128 x 128 launch;
+     *                     bit-identical to the four-wave tile */
+    int32_t tile_cfg, persist, general_epilogue, small_w8;
 } kai0_gemm_desc;
 
 int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream);
 /* sizeof(kai0_gemm_desc) as compiled: lets a foreign-language binding verify its struct mirror */
 int kai0_gemm_desc_size(void);
-/* Diagnostics: force a tile / schedule configuration of kai0_gemm_bf16 (0 = automatic choice, the default; values as the
- * KAI0_GEMM_CFG environment variable, see gemm_bf16.hip).  Returns the previous setting.  Not thread-safe. */
-int kai0_gemm_set_cfg(int cfg);
-/* Persistent NT kernel (one resident block per CU drawing 256 x 256 tiles from an atomic, XCD-grouped ticket queue; the next tile's
- * first half-tiles are staged before the current tile's epilogue): 0 = never, 1 = for K-contiguous one-entry GEMMs of >= 512 tiles with
- * a fused GeGLU / GELU epilogue or K <= 2048 (default; env KAI0_GEMM_PERSIST), 2 = every eligible NT launch.  Results are bit-identical
- * to the one-block-per-tile launches.  Returns the previous mode. */
-int kai0_gemm_set_persist(int mode);
-/* Diagnostics: 0 sends the 256 x 256 launches whose epilogue is a store with little else (act 0 / 1, optional bias / residual / column
- * routing; no gate, accumulate, f32 output, scale or row map) through the general per-row epilogue instead of their fast path (default 1).
- * Both produce the same bits (tests/test_kernels_gpu.py).  Returns the previous setting.  Not thread-safe. */
-int kai0_gemm_set_simple_epilogue(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Few-row weight-streaming GEMM for the denoise loop (B*action_horizon <= a few 64-row tiles):

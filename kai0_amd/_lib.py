@@ -46,6 +46,7 @@ class GemmDesc(C.Structure):
         ("B2", c_p), ("pre_out2", c_p),
         ("norm_out", c_p), ("norm_w", c_p), ("norm_b", c_p), ("norm_eps", C.c_float), ("norm_kind", C.c_int32),
         ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", C.c_int32), ("rope_n_end", C.c_int32),
+        ("tile_cfg", C.c_int32), ("persist", C.c_int32), ("general_epilogue", C.c_int32), ("small_w8", C.c_int32),
     ]  # fmt: skip
 
 
@@ -119,9 +120,6 @@ class SkinnyDesc(C.Structure):
 _PROTOS: dict[str, list] = {
     "kai0_abi_version": [],
     "kai0_gemm_desc_size": [],
-    "kai0_gemm_set_cfg": [c_i],
-    "kai0_gemm_set_persist": [c_i],
-    "kai0_gemm_set_simple_epilogue": [c_i],
     "kai0_device_info": [c_i, C.POINTER(c_i), C.POINTER(c_i), C.c_char_p],
     "kai0_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "kai0_attn_fwd": [C.POINTER(AttnDesc), c_p],

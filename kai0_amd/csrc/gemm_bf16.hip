@@ -74,7 +74,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int ablate;  // diagnostics only (KAI0_GEMM_ABLATE=1): no DMA inside the K loop (compute-only ceiling)
     int nt_c;    // C stored non-temporally (kai0hip.h c_nontemporal: weight gradients, read again only by the optimizer)
-    int simple_epi;  // the store-with-little-else fast epilogue may be used (kai0_gemm_set_simple_epilogue, tests)
+    int simple_epi;  // the store-with-little-else fast epilogue may be used (kai0_gemm_desc.general_epilogue == 0)
     int nt_pre;  // pre-activation outputs (pre_out / pre_out2 of act 1 and 6: read again only by the backward) stored non-temporally
     const float* rowvec;   // act 4: per-row f32 vector D (softmax backward), index z1*rv_s1 + z2*rv_s2 + row*rv_ld
     int64_t rv_s1, rv_s2, rv_ld;
@@ -300,7 +300,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     constexpr int A_LPR = A_ROWB / 16, B_LPR = B_ROWB / 16;  // 16-B chunks (= lanes) per such row
     constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;    // k-rows per DMA piece
     constexpr int GROUP = TBM == 128 ? 8 : 4;
-    static_assert(NA >= 1 && NB >= 1 && NT == 4 && (MT % 4) == 0, "unsupported tile configuration");
+    static_assert(NA >= 1 && NB >= 1 && NT == 4 && ((MT % 4) == 0 || MT == 2), "unsupported tile configuration");
+    constexpr int AH = MT >= 4 ? 4 : MT;  // 16-row MFMA tiles per epilogue pass / A-fragment group (64 rows; 32 for the 8-wave 128 x 128 tile)
     static_assert(A_KC || (64 % A_LPR) == 0, "contraction-strided A needs a power-of-two tile height");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    if constexpr (MT == 4) {
+    if constexpr (MT <= 4) {
         // 128 x 128 configurations (the B = 1 inference GEMMs: a launch is ~20 us, ~190 of them per action chunk): every kernel
         // argument the prologue needs is pulled into SGPRs in ONE batch of scalar loads.  Left to itself hipcc loads each field of
         // the by-value struct next to its first use: six serial s_load / s_waitcnt round trips stood in front of the first LDS-DMA.
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
         if (grp == 0) lds_barrier();  // re-align the two groups
         lds_barrier();
     } else if constexpr (PP) {
-        // Two-buffer ping-pong (kept for comparison, KAI0_GEMM_CFG=5).  Barrier clock b0, b1, ...: per K-tile t group 0 runs
+        // Two-buffer ping-pong (kept for comparison, kai0_gemm_desc.tile_cfg = 5).  Barrier clock b0, b1, ...: per K-tile t group 0 runs
         // L0(t) |b| M0(t) |b| L1(t) |b| M1(t) |b|  and group 1 the same sequence one barrier later.  Lk = [k = 0: issue the
         // whole DMA of tile t+1] + the 12 fragment reads of k-half k; Mk = its 32 MFMAs.
         //  * RAW: tile t+1 is first read after barrier 4t+3 (group 0's L0(t+1)); every wave drains its own DMA before
@@ -791,15 +792,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     #pragma unroll
                 for (int t = 0; t < NT; ++t) bfr[t] = load_frag(tb, B_KC, B_ROWB, wn * (NT * 16) + t * 16, ks);
     #pragma unroll
-                for (int h = 0; h < MT / 4; ++h) {  // A fragments 4 at a time: bounds the live registers of the 8x4 tiling
-                    bf16x8 af[4];
+                for (int h = 0; h < MT / AH; ++h) {  // A fragments 4 at a time: bounds the live registers of the 8x4 tiling
+                    bf16x8 af[AH];
     #pragma unroll
-                    for (int t = 0; t < 4; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + (h * 4 + t) * 16, ks);
+                    for (int t = 0; t < AH; ++t) af[t] = load_frag(ta, A_KC, A_ROWB, wm * (MT * 16) + (h * AH + t) * 16, ks);
     #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < AH; ++i)
     #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+                            acc[h * AH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * AH + i][j], 0, 0, 0);
                 }
             }
             slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     // 256x256 configurations: the store-with-little-else epilogues (act 0 / 1, optional bias, optional residual, optional column routing,
     // optional accumulation into the bf16 destination; no gate / f32 output / scale / row map) without the general path's per-row checks of everything else — measured in
     // the persistent kernel: 9.7 -> 4.6 us per tile for a plain store (profiles/r05_gemm_persistent_phases.txt).  Same order and rounding
-    // points as epilogue8; kai0_gemm_set_simple_epilogue(0) sends these launches through the general path (tests).
+    // points as epilogue8; kai0_gemm_desc.general_epilogue = 1 sends these launches through the general path (tests).
     const bool simple_fast = MT == 8 && p.simple_epi && p.act <= 1 && p.split_k == 1 && p.gate == nullptr && !p.out_f32 && p.scale == 1.0f &&
                              p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
     auto epi_half = [&](auto hc) {
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             }
             return;
         }
-        if (pair) {
+        if constexpr (MT != 2) if (pair) {
             // GeGLU in registers: slab columns [0, 32) = gate, [32, 64) = up of the wave's 32 output columns n0/2 + wn*32 + ..;
             // each lane takes 8 of them for one row (16 rows per pass).  Rounding points of act 2: g = bf16(acc), u = bf16(acc),
             // h = bf16(bf16(gelu_tanh(g)) * u)
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             __builtin_amdgcn_wave_barrier();
             return;
         }
-        if (fused_fast) {
+        if constexpr (MT != 2) if (fused_fast) {
             bf16x8 s0[8], s1[8];
             float ds[8];
             const int rbase = row_base(h) + (lane >> 3);
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             __builtin_amdgcn_wave_barrier();
             return;
         }
-        if constexpr (MT == 4) if (plain_fast) {  // (128x128 configurations: in the 256x256 kernels the operand registers went to scratch)
+        if constexpr (MT <= 4) if (plain_fast) {  // (128x128 configurations: in the 256x256 kernels the operand registers went to scratch)
             // bias / GELU / residual epilogue with its operands requested up front: the bias once (a lane's 8 columns are the same for
             // all of its rows), the 8 residual rows of the half before the accumulators go to the slab.  In the rolled loop below every
             // iteration waited out a bias and a residual round trip of its own — most of the fixed cost of the small (B = 1) GEMMs.
@@ -1041,25 +1042,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                     for (int e = 0; e < 8; ++e) bv[e] = bf2f(b[e]);
                 }
             }
-            bf16x8 rs[8];
+            bf16x8 rs[AH * 2];
             const int rbase = row_base(h) + (lane >> 3);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < AH * 2; ++it) {
                 const int row = rbase + it * 8;
                 rs[it] = bf16x8{};
                 if (p.residual != nullptr && row < p.M && col_ok) rs[it] = *reinterpret_cast<const bf16x8*>(p.residual + rz + p.cmap(row) * p.ldr + ccol);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < AH; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+                    for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * AH + i][j][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             bf16_t* cb = reinterpret_cast<bf16_t*>(p.C);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < AH * 2; ++it) {
                 const int row = rbase + it * 8;
                 const float* sp = slab + (it * 8 + (lane >> 3)) * 64 + (lane & 7) * 8;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
@@ -1206,15 +1207,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < AH; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * 4 + i][j][r];
+                for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[h * AH + i][j][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < AH * 2; ++it) {
             const int lr = it * 8 + (lane >> 3);
             const int row = row_base(h) + lr;
             if (row >= p.M || !col_ok) continue;
@@ -1898,35 +1899,13 @@ int launch_cfg(const kai0_gemm_desc* d, GemmArgs& p, int batch, hipStream_t s) {
     return 0;
 }
 
-int g_gemm_cfg = 0;  // kai0_gemm_set_cfg (tools / tests): no environment switch
-int g_gemm_simple_epi = 1;  // kai0_gemm_set_simple_epilogue
-int g_gemm_persist = [] { const char* e = getenv("KAI0_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-
 }  // namespace
-
-KAI0_API int kai0_gemm_set_cfg(int cfg) {
-    const int old = g_gemm_cfg;
-    g_gemm_cfg = cfg;
-    return old;
-}
 
 #ifdef KAI0_PS_TRACE
 KAI0_API int kai0_debug_ps_trace(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ps_trace), sizeof(long long) * 256 * 8);
 }
 #endif
-
-KAI0_API int kai0_gemm_set_simple_epilogue(int on) {
-    const int old = g_gemm_simple_epi;
-    g_gemm_simple_epi = on;
-    return old;
-}
-
-KAI0_API int kai0_gemm_set_persist(int mode) {
-    const int old = g_gemm_persist;
-    g_gemm_persist = mode;
-    return old;
-}
 
 KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     KAI0_REQUIRE(d != nullptr, "kai0_gemm_bf16: null descriptor");
@@ -2037,7 +2016,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // caller sets c_nontemporal (weight gradients)
     p.nt_pre = 1;
     p.nt_c = d->c_nontemporal != 0;
-    p.simple_epi = g_gemm_simple_epi;
+    p.simple_epi = d->general_epilogue == 0;
     p.rowvec = d->rowvec; p.rv_s1 = d->rv_s1; p.rv_s2 = d->rv_s2; p.rv_ld = d->rv_ld;
     p.nseg = d->nseg;
     for (int i = 0; i < 3; ++i) {
@@ -2059,7 +2038,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     }
     // tile configuration: 256x256 (1 block of 8 waves per CU, half the staged bytes per FLOP) when the problem gives
     // (nearly) every CU a block; 128x128 (2 blocks per CU) for small problems.
-    const int forced = g_gemm_cfg;
+    const int forced = d->tile_cfg;
     const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((p.N + 255) / 256) * batch * (split > 1 ? split : 1);
     const bool big = d->act == 7 ? false : (forced ? forced >= 4 : (big_tiles >= 160 && d->K >= 256));  // (act 7: 128-column tiles)
     hipStream_t s = (hipStream_t)stream;
@@ -2070,7 +2049,13 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // few 128x128 tiles (at most one block per CU): nothing else hides the load latency -> 4-stage pipeline
     const int64_t small_blocks = (int64_t)((d->M + 127) / 128) * ((p.N + 127) / 128) * batch * (split > 1 ? split : 1);
     const bool deep = forced ? forced == 2 : (small_blocks <= 256 && p.k_chunk >= 256);
-    // forced (KAI0_GEMM_CFG / kai0_gemm_set_cfg, A/B runs): 1 / 2 = 128x128 with 2 / 4 stages, 4 = 256x256 plain loop, 5 = 256x256
+    // 128 x 128 on EIGHT waves (4 x 2 wave tiles of 32 x 64; round 6): with at most one block per CU the four-wave loop has one wave per
+    // SIMD, so a K-tile is that wave's 8 LDS-DMA issues + 16 fragment reads + 32 MFMAs one after the other (~1470 clocks for 544 of MFMA);
+    // two waves per SIMD let one wave's MFMAs run under the other's DMA issue and read latency.  K-contiguous operands, act 0 / 1 (the
+    // epilogues the narrower wave tile implements); kai0_gemm_desc.small_w8: 0 = this rule, 1 = never, 2 = every eligible 128 x 128 launch.
+    const bool w8_ok = !big && d->a_kc && d->b_kc && d->act <= 1 && (forced == 0 || forced == 3);
+    const bool w8 = w8_ok && (forced == 3 || d->small_w8 == 2 || (d->small_w8 == 0 && deep));
+    // forced (kai0_gemm_desc.tile_cfg, A/B runs): 1 / 2 = 128x128 with 2 / 4 stages, 4 = 256x256 plain loop, 5 = 256x256
     // two-buffer ping-pong for every layout.  Measured (MLP shapes, random data): the 32-deep ring wins +21 % for the transpose-read
     // layout (TN wgrads: 512-B source rows, so a 32-deep sub-tile still moves whole cache lines) and loses up to 17 % for NT (64-B
     // source rows = half lines), which runs the quadrant schedule (+6..10 % over the two-buffer ping-pong, 1.37 PFLOP/s at 8192^3).
@@ -2078,8 +2063,8 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     // plain tile (equal to the ping-pong, spilled), the quadrant schedule with its DMA pieces between the MFMAs, the ring with two
     // pieces per slot kind (-0.9 %), the ring for NT.
     const bool ring = !forced && d->act != 6 && !d->a_kc && !d->b_kc;
-    // persistent NT kernel with the dynamic tile queue (KAI0_GEMM_PERSIST: 0 never, 1 = the rule below, 2 = every eligible NT launch)
-    const int persist = g_gemm_persist;
+    // persistent NT kernel with the dynamic tile queue (kai0_gemm_desc.persist: 0 = the rule below, 1 = never, 2 = every eligible NT launch)
+    const int persist = d->persist == 1 ? 0 : (d->persist == 2 ? 2 : 1);
     const bool ps_ok = !forced && persist && big && d->a_kc && d->b_kc && batch == 1 && split == 1 &&
                        big_tiles >= (persist == 2 ? 512 : 2048) &&  // (B = 1 prefix MLP, 512 tiles = two per CU: 97 -> 136 us persistent)
                        (p.K % 8) == 0 && !d->rowvec && d->a_rpb == 0 && d->b_rpb == 0;
@@ -2119,6 +2104,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     else if (big && d->b_kc && forced != 5) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);  // NT: quadrant schedule
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);
+    else if (w8) rc = launch_cfg<4, 2, 2, 4, false, 4>(d, p, batch, s);
     else if (deep) rc = launch_cfg<2, 2, 4, 4, false, 4>(d, p, batch, s);
     else rc = launch_cfg<2, 2, 4, 4, false>(d, p, batch, s);
     if (rc) return rc;

@@ -13,6 +13,7 @@ is done by libkai0hip.so.  There is deliberately no CPU / eager fallback.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import math
@@ -47,6 +48,27 @@ def _chk(t: torch.Tensor, dtype, name: str) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+# The A/B and test hooks of kai0_gemm_desc (kai0hip.h: tile_cfg / persist / general_epilogue), all 0 in production.  They travel with
+# every call's descriptor — the library itself has no process-wide switch; tests and tools set them through `gemm_tuning(...)`.
+# (KAI0_GEMM_PERSIST=0 / 1 / 2 — never / the library's rule / every eligible NT launch — is read HERE, on the host side of the boundary.)
+GEMM_TUNING = {"tile_cfg": 0, "persist": {"0": 1, "2": 2}.get(os.environ.get("KAI0_GEMM_PERSIST", "1"), 0), "general_epilogue": 0,
+               "small_w8": int(os.environ.get("KAI0_GEMM_W8", "0"))}
+
+
+@contextlib.contextmanager
+def gemm_tuning(**kw):
+    """with ops.gemm_tuning(persist=2): ...  — descriptor hooks for the GEMM launches made inside the block."""
+    unknown = set(kw) - set(GEMM_TUNING)
+    if unknown:
+        raise KeyError(f"gemm_tuning: unknown hook(s) {sorted(unknown)}")
+    old = dict(GEMM_TUNING)
+    GEMM_TUNING.update(kw)
+    try:
+        yield
+    finally:
+        GEMM_TUNING.update(old)
+
+
 def gemm(
     A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, a_kc: bool = True,
     b_kc: bool = True, lda: int, ldb: int, ldc: int, batch: int = 1, batch_inner: int = 1,
@@ -130,6 +152,8 @@ def gemm(
         if nb is not None:
             _chk(nb, BF16, "gemm: norm bias")
             d.norm_b = nb.data_ptr()
+    d.tile_cfg, d.persist, d.general_epilogue, d.small_w8 = (GEMM_TUNING["tile_cfg"], GEMM_TUNING["persist"], GEMM_TUNING["general_epilogue"],
+                                                               GEMM_TUNING["small_w8"])
     _lib.call("kai0_gemm_bf16", C.byref(d), _stream())
     return out
 
@@ -300,7 +324,7 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
     if M <= 128:  # one row of tiles: pure weight streaming, latency-bound -> chunks as short as 2 K-tiles
         return max(1, min(32, 768 // tiles, K // 128))
     # a few hundred to a few thousand rows (the action expert at B = 32, the B = 1 prefix pass): measured on MI355X
-    # (tools/expert_gemm_probe.py, us per call over split 1..8): ~400 blocks of 128x128 in total with chunks of >= 768 is the
+    # (a sweep of us per call over split 1..8, round 2): ~400 blocks of 128x128 in total with chunks of >= 768 is the
     # optimum; the former rule (up to 768 blocks, chunks down to 256) cost 20-60 % on these shapes
     return max(1, min(round(400 / tiles), K // 768))
 

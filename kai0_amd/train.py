@@ -48,7 +48,9 @@ class Trainer:
         self._param_order = [n for n, _ in model.named_parameters()]  # torch's optimizer indexing (ties once)
         named = [(n, p) for n, p in model.named_parameters() if p is not dead]
         units = model.sharding_units() if hasattr(model, "sharding_units") else None
-        mode = mode or os.environ.get("KAI0_SHARD_MODE", "zero2")
+        # north_star's partition — optimizer state, gradients AND parameters sharded (fsdp) — is the default whenever there are peers;
+        # KAI0_SHARD_MODE=zero2 / mode="zero2" keeps the parameters replicated (optimizer state and gradients sharded only)
+        mode = mode or os.environ.get("KAI0_SHARD_MODE") or ("fsdp" if world_size > 1 else "zero2")
         if bucket_bytes is None:
             bucket_bytes = int(os.environ.get("KAI0_BUCKET_MB", "256" if mode == "fsdp" else "512")) << 20
         if prefetch is None:

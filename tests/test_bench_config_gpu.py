@@ -14,8 +14,10 @@ vocab 2048; the launches that only exist at M = 30 976 were covered as isolated 
       rows a step touches against `torch.optim.AdamW(betas 0.9 / 0.95, eps 1e-8, wd 1e-10)` fed the same clipped gradients (f32
       masters within 2 f32 ulp, both moments within 1e-5 of torch's optimizer state, the bf16 rows within one ulp); rows never touched
       stay bit-identical with zero moments; the engine's row-activity flags name exactly the rows of valid prompt tokens.
-Reference: pi0_pytorch.py:316-373, train_pytorch.py:547-567, optimizer.py:15-85.  Figures -> gpurun_out/parity_r05.txt (committed as
-profiles/parity_r05.txt)."""
+Reference: pi0_pytorch.py:316-373, train_pytorch.py:547-567, optimizer.py:15-85.
+  (a'') round 6: the B = 32 launch with the loss masked to samples {0, 17}: every gradient DIRECTLY against the fp32 oracle's backward
+      on those two samples, per-parameter bound <= 1.5 x (bf16 oracle's own error) + 2e-3.
+Figures -> gpurun_out/parity_b32.txt (committed as profiles/parity_r06_b32.txt), tables grad_table_b32*.txt."""
 
 import os
 import sys
@@ -30,7 +32,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 F32, BF16 = torch.float32, torch.bfloat16
-REPORT = os.path.join("gpurun_out", "parity_r05.txt")
+REPORT = os.path.join("gpurun_out", "parity_b32.txt")
 B = 32
 VOCAB = 257152
 
@@ -205,7 +207,98 @@ def test_b32_loss_rows_match_the_fp32_oracle_on_two_samples(bc):
     _report(f"(a') loss rows of samples {pick} of the B = 32 launch vs the fp32 oracle (vocab {VOCAB}, token ids up to "
             f"{int(cobs.tokenized_prompt.max())}): rel-L2 {rs[0]:.3e} / {rs[1]:.3e}  (oracle build {t1 - t0:.1f} s, forward {time.time() - t1:.1f} s)")  # fmt: skip
     assert max(rs) <= 1e-2
-    del o32
+    bc["state"].update(o32=o32, cobs=cobs, pick=pick)  # the next test runs this oracle backward
+
+
+def _bf16_oracle(model):
+    """the reference's own mixed bf16 choreography at the benchmarked vocabulary, same weights"""
+    from fulldepth import host_state
+    from oracle import pi0_oracle as O
+
+    state = host_state(model)
+    with torch.device("meta"):
+        obf = O.OraclePI0(O.OracleConfig(dtype="bfloat16", vocab_size=VOCAB))
+    obf.to_empty(device="cpu")
+    with torch.no_grad():
+        obf.load_state_dict(state, strict=True)
+        for mod in obf.modules():
+            if isinstance(getattr(mod, "inv_freq", None), torch.Tensor):
+                mod.inv_freq = O.rope_inv_freq(mod.inv_freq.numel() * 2).to(BF16)
+            if isinstance(mod, O.SiglipVisionEmbeddings):
+                mod.position_ids = torch.arange(mod.num_patches).expand((1, -1))
+    return obf
+
+
+def test_b32_masked_gradients_match_the_fp32_oracle_backward_on_two_samples(bc):
+    """VERDICT r5 "next round" #4 — the last indirection at the benchmarked configuration: test (a) compares the B = 32 gradients with the
+    HIP B = 1 path, i.e. with the oracle only transitively.  Here the B = 32 launch runs under the same Trainer with the loss masked to
+    samples {0, 17} (`losses[pick].mean().backward()`: the other 30 samples still go through every kernel of the launch, their
+    cotangents are zero), and all gradients are compared DIRECTLY with the fp32 oracle's backward on those two samples, under the
+    per-parameter bound of tests/test_fulldepth_gpu.py: HIP-vs-fp32 <= 1.5 x (bf16-oracle-vs-fp32) + 2e-3 and <= 5e-2, the bf16 oracle
+    being the reference's own choreography run through autograd on the same two samples (pi0_pytorch.py:316-373)."""
+    st = bc["state"]
+    if "o32" not in st or "trainer" not in st:
+        pytest.skip("needs the Trainer and the fp32 oracle of the previous tests")
+    model, dev, obs, actions, noise, tm = bc["model"], bc["dev"], bc["obs"], bc["actions"], bc["noise"], bc["time"]
+    o32, cobs, pick = st.pop("o32"), st["cobs"], st["pick"]
+    eng = st["trainer"].engine
+    st["pending_step"] = False  # this backward overwrites the flat gradients of test (a): test (b) runs its own first step
+    eng.begin_step()
+    losses = model(obs, actions, noise=noise, time=tm)
+    losses[pick].mean().backward()
+    torch.cuda.synchronize()
+    names = {id(p): n for n, p in model.named_parameters()}
+    got = {}
+    for b in eng.buckets:
+        for p, o in zip(b.params, b.offsets):
+            got[names[id(p)]] = b.flat_grad[o : o + p.numel()].view(p.shape)
+    ca, cn, ct = actions[pick].cpu(), noise[pick].cpu(), tm[pick].cpu()
+    t0 = time.time()
+    o32.zero_grad(set_to_none=True)
+    o32(cobs, ca, cn, ct).mean().backward()
+    t32 = time.time() - t0
+    t0 = time.time()
+    obf = _bf16_oracle(model)
+    obf(cobs, ca, cn, ct).mean().backward()
+    gbf = {n: p.grad for n, p in obf.named_parameters() if p.grad is not None}
+    tbf = time.time() - t0
+    table, bad, none_both = [], [], 0
+    for n, p in o32.named_parameters():
+        g = p.grad
+        if n not in got:  # the oracle's tied lm_head copy after to_empty / the dead expert lm_head: not trained
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        h = got[n]
+        if g is None or float(g.norm()) < 1e-9:
+            assert float(h.float().abs().max()) < 1e-5, n
+            none_both += 1
+            continue
+        if "vision_tower" in n and n.endswith("self_attn.k_proj.bias"):  # exact gradient zero (softmax shift invariance): noise on both sides
+            ref_scale = float(o32.get_parameter(n.replace("k_proj.bias", "q_proj.bias")).grad.norm())
+            assert float(g.norm()) <= 1e-2 * ref_scale and float(h.float().norm()) <= 1e-2 * ref_scale, n
+            continue
+        gd = g.to(dev)
+        r = grel(h, gd)
+        rb = grel(gbf[n].to(dev), gd) if n in gbf else float("nan")
+        table.append((r, n, float(g.norm()), rb))
+        if r > 5e-2 or (rb == rb and r > 1.5 * rb + 2e-3):
+            bad.append((r, rb, n))
+    table.sort(reverse=True)
+    with_bf = [t for t in table if t[3] == t[3]]
+    worst_ratio = max(with_bf, key=lambda t: t[0] / (1.5 * t[3] + 2e-3))
+    _report(f"(a'') gradients of mean(loss[{pick}]) from the B = 32 Trainer launch (loss masked to two samples) vs ONE fp32 oracle backward on those "
+            f"samples: {len(table)} parameters, worst rel-L2 {table[0][0]:.3e} ({table[0][1]}), median {table[len(table) // 2][0]:.3e}; the bf16 oracle's "
+            f"backward vs the same fp32 gradients: worst {max(t[3] for t in with_bf):.3e}, median {sorted(t[3] for t in with_bf)[len(with_bf) // 2]:.3e}; "
+            f"HIP / (1.5 x bf16-oracle + 2e-3) at most {worst_ratio[0] / (1.5 * worst_ratio[3] + 2e-3):.2f} ({worst_ratio[1]}); {none_both} parameters without a "
+            f"gradient on both sides  (fp32 oracle fwd+bwd {t32:.1f} s, bf16 oracle build + fwd+bwd {tbf:.1f} s)")  # fmt: skip
+    with open(os.path.join("gpurun_out", "grad_table_b32_oracle.txt"), "w") as f:
+        f.write("# rel-L2 of d mean(loss[0, 17]) / d parameter, B = 32 Trainer launch with the loss masked to two samples, against ONE fp32 oracle "
+                "backward on those samples: HIP | bf16-choreography oracle | |g| | name\n")
+        for r, n, gn, rb in table:
+            f.write(f"{r:.3e}  {rb:.3e}  |g|={gn:.3e}  {n}\n")
+    del o32, obf, gbf
+    assert not bad, f"{len(bad)} gradient mismatches, worst: {sorted(bad, reverse=True)[:5]}"
+    assert len(table) >= 700
 
 
 def test_two_trainer_steps_at_full_vocab_match_torch_adamw_on_the_touched_rows(bc):

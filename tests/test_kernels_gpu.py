@@ -1130,7 +1130,7 @@ def test_siglip_attention_backward_fused_matches_gemm_path_and_fp32(ops):
 @pytest.mark.parametrize("case", ["plain", "bias", "bias_f32", "bias_res", "res", "gelu_pre", "gelu_res", "routed", "ragged_rows", "batched", "tn", "accum", "accum_res"])
 def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persist):
     """256 x 256 launches whose epilogue is a store with little else (act 0 / 1, bias, residual, column routing) take a fast path that
-    skips the general epilogue's per-row checks (also when it accumulates into the destination); kai0_gemm_set_simple_epilogue(0) sends them through the general path: same bits in
+    skips the general epilogue's per-row checks (also when it accumulates into the destination); kai0_gemm_desc.general_epilogue = 1 sends them through the general path: same bits in
     every output, in the one-block-per-tile kernels (persist 0) and in the persistent kernel (persist 2), with ragged rows, batch
     entries (their C / residual strides) and the transpose-read layout of the weight gradients."""
     from kai0_amd import _lib
@@ -1166,10 +1166,8 @@ def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persis
     elif case == "accum_res":
         kw = dict(accumulate=True, bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N)
     res = {}
-    try:
-        lib.kai0_gemm_set_persist(persist)
-        for simple in (0, 1):
-            lib.kai0_gemm_set_simple_epilogue(simple)
+    for simple in (0, 1):
+        with ops.gemm_tuning(persist=2 if persist == 2 else 1, general_epilogue=1 - simple):
             outs = [torch.full((batch * M, N), 3.0, dtype=BF16, device=dev()) for _ in range(nout)]
             k2 = dict(kw)
             if nout >= 2:
@@ -1181,9 +1179,6 @@ def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persis
             ops.gemm(A, W, outs[0], M=M, N=N, K=K, ldc=N, **lay, **k2)
             torch.cuda.synchronize()
             res[simple] = outs
-    finally:
-        lib.kai0_gemm_set_simple_epilogue(1)
-        lib.kai0_gemm_set_persist(1)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
     if case == "plain":
@@ -1192,9 +1187,57 @@ def test_simple_epilogue_fast_path_equals_the_general_epilogue(ops, case, persis
         assert not torch.equal(res[1][1], torch.full_like(res[1][1], 3.0))  # the routed destinations were written
 
 
+@pytest.mark.parametrize("case", ["plain", "bias", "bias_res", "gelu_pre", "split", "split_norm", "routed", "rowmap", "ragged", "fc2"])
+def test_eight_wave_128_tile_is_bit_identical_to_the_four_wave_tile(ops, case):
+    """kai0_gemm_desc.small_w8: the 128 x 128 tile run by eight waves (4 x 2 wave tiles of 32 x 64, two waves per SIMD — round 6, for the
+    B = 1 passes whose grids are at most one block per CU) against the four-wave tile: the same products in the same order, so every
+    output must have the same bits — plain / bias / residual / GELU + pre-activation epilogues, split-K partials (and the norm fused into
+    their reduction), column routing, output row maps, ragged edges and a K tail."""
+    M, N, K = {"ragged": (700, 1160, 1160), "fc2": (768, 1152, 4304)}.get(case, (768, 1152, 1152))
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    kw, nout = {}, 1
+    if case == "bias":
+        kw = dict(bias=rnd(N, seed=3))
+    elif case in ("bias_res", "ragged", "fc2"):
+        kw = dict(bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N)
+    elif case == "gelu_pre":
+        kw, nout = dict(bias=rnd(N, seed=3), act=1), 2
+    elif case == "split":
+        kw = dict(split_k=3, bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N)
+    res = {}
+    for mode in (1, 2):
+        with ops.gemm_tuning(small_w8=mode):
+            outs = [torch.full((M, N), 3.0, dtype=BF16, device=dev()) for _ in range(nout)]
+            k2 = dict(kw)
+            if nout >= 2:
+                k2["pre_out"] = outs[1]
+            if case == "split_norm":  # LayerNorm of the rows inside the reduction launch
+                nout_t = torch.full((M, N), 3.0, dtype=BF16, device=dev())
+                k2.update(split_k=3, bias=rnd(N, seed=3), residual=rnd(M, N, seed=4), ldr=N,
+                          norm=(2, nout_t, rnd(N, seed=5), rnd(N, seed=6), 1e-6))
+                outs = outs + [nout_t]
+            if case == "routed":
+                dst = [torch.full((M, w), 3.0, dtype=BF16, device=dev()) for w in (N // 2, N // 4, N // 4)]
+                k2["segs"] = [(dst[0], N // 2, 0), (dst[1], N // 4, N // 2), (dst[2], N // 4, 3 * N // 4)]
+                outs = outs + dst
+            if case == "rowmap":  # rows of 3 "batch entries" of 256 into a buffer padded to 320 rows each, from row 8
+                big = torch.full((3 * 320, N), 3.0, dtype=BF16, device=dev())
+                k2["c_map"] = (256, 320, 8)
+                outs = [big]
+            ops.gemm(A, W, outs[0], M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **k2)
+            torch.cuda.synchronize()
+            res[mode] = outs
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b)
+    if case == "plain":
+        assert rel_err(res[2][0], A.float() @ W.float().t()) < 5e-3
+    if case == "routed":
+        assert not torch.equal(res[2][1], torch.full_like(res[2][1], 3.0))
+
+
 @pytest.mark.parametrize("case", ["plain", "bias_res", "gelu_pre", "geglu_pair", "geglu_fwd", "geglu_bwd", "gelu_bwd", "ragged"])
 def test_persistent_gemm_is_bit_identical_to_one_block_per_tile(ops, case):
-    """kai0_gemm_set_persist(2): the persistent NT kernel (dynamic per-XCD tile queue, next tile staged before the epilogue, 16-row
+    """kai0_gemm_desc.persist = 2: the persistent NT kernel (dynamic per-XCD tile queue, next tile staged before the epilogue, 16-row
     epilogue slabs) against the one-block-per-tile launches on every epilogue it serves: same bits, every output (C, pre_out,
     pre_out2), including ragged edges and more tiles than resident blocks."""
     from kai0_amd import _lib
@@ -1216,9 +1259,8 @@ def test_persistent_gemm_is_bit_identical_to_one_block_per_tile(ops, case):
     elif case == "gelu_bwd":
         kw = dict(act=5, aux1=rnd(M, N, seed=6))
     res = {}
-    try:
-        for mode in (0, 2):
-            lib.kai0_gemm_set_persist(mode)
+    for mode in (0, 2):
+        with ops.gemm_tuning(persist=2 if mode == 2 else 1):
             outs = [torch.full((M, N), 3.0, dtype=BF16, device=dev()) for _ in range(nout)]
             k2 = dict(kw)
             if nout >= 2:
@@ -1228,8 +1270,6 @@ def test_persistent_gemm_is_bit_identical_to_one_block_per_tile(ops, case):
             ops.gemm(A, W, outs[0], M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **k2)
             torch.cuda.synchronize()
             res[mode] = outs
-    finally:
-        lib.kai0_gemm_set_persist(1)
     for a, b in zip(res[0], res[2]):
         assert torch.equal(a, b)
     ref = A.float() @ W.float().t()  # and it is the right product (plain case: against fp32)

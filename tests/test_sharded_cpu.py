@@ -429,10 +429,11 @@ def test_reference_style_optimizer_state_loads():
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-5)
 
 
-def test_flat_gradients_of_parameters_without_a_new_gradient_count_as_zero(monkeypatch):
+def test_flat_gradients_of_parameters_without_a_new_gradient_count_as_zero():
     """The flat gradient buffers are not cleared after a step (producers overwrite their slices): a parameter that got a
-    gradient in step t but none in step t+1 must enter step t+1 as zero, not with its old gradient.  Reference: the same
-    engine with the full clear after every step (KAI0_ZERO_GRADS=full)."""
+    gradient in step t but none in step t+1 must enter step t+1 as zero, not with its old gradient.  Two independent references:
+    the same engine with every flat buffer cleared by hand after each step (what the lazy bookkeeping must be equivalent to), and
+    torch.optim.AdamW + clip_grad_norm_ on a plain copy of the module with `zero_grad()` between the steps."""
     from kai0_amd.sharded import ShardedDataParallel
 
     class TwoBranch(torch.nn.Module):
@@ -444,25 +445,43 @@ def test_flat_gradients_of_parameters_without_a_new_gradient_count_as_zero(monke
         def forward(self, x, use_b):
             return self.a(x).sum() + (self.b(x).pow(2).sum() if use_b else 0.0)
 
-    def run(mode):
-        if mode:
-            monkeypatch.setenv("KAI0_ZERO_GRADS", mode)
-        else:
-            monkeypatch.delenv("KAI0_ZERO_GRADS", raising=False)
+    x = torch.linspace(-1, 1, 12).reshape(2, 6)
+    schedule = (True, False, False, True)
+
+    def run(full_clear):
         m = TwoBranch()
         eng = ShardedDataParallel(m.parameters(), world_size=1, rank=0, ops=TorchShardOps(), weight_decay=0.0, max_grad_norm=10.0,
                                   bucket_bytes=64)  # fmt: skip
         norms = []
-        x = torch.linspace(-1, 1, 12).reshape(2, 6)
-        for use_b in (True, False, False, True):
+        for use_b in schedule:
             m(x, use_b).backward()
             norms.append(float(eng.step(1e-2)))
+            if full_clear:  # the reference arm: nothing of this step's gradients survives into the next one
+                for b in eng.buckets:
+                    b.flat_grad.zero_()
+                    b.stale.clear()
         return [p.detach().clone() for p in m.parameters()], norms
 
-    lazy, n_lazy = run(None)
-    full, n_full = run("full")
+    lazy, n_lazy = run(False)
+    full, n_full = run(True)
     assert n_lazy == n_full and n_lazy[1] < n_lazy[0]  # steps 2, 3 see no gradient for branch b
     assert all(torch.equal(a, b) for a, b in zip(lazy, full))
+    # ... and torch's own optimizer on a plain module whose gradients are ZEROED (not dropped) between the steps: the semantics the
+    # flat buffers must reproduce (a zero gradient still decays the moments and applies them)
+    ref = TwoBranch()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0)
+    n_ref = []
+    for use_b in schedule:
+        opt.zero_grad(set_to_none=False)
+        for q in ref.parameters():
+            if q.grad is None:
+                q.grad = torch.zeros_like(q)
+        ref(x, use_b).backward()
+        n_ref.append(float(torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)))
+        opt.step()
+    assert all(abs(a - b) <= 1e-5 * max(a, 1e-6) for a, b in zip(n_ref, n_lazy))
+    for a, b in zip(lazy, ref.parameters()):
+        assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
 
 
 def test_checkpoint_helpers_roundtrip_with_flat_buffers(tmp_path):

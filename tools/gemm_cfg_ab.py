@@ -3,7 +3,7 @@ auto rule against the forced 128x128 (2 blocks per CU) and 256x256 configuration
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from kai0_amd import _lib
+from kai0_amd import _lib, ops
 from kai0_amd.ops import gemm
 dev = torch.device("cuda:0"); BF16 = torch.bfloat16
 lib = _lib.load()
@@ -36,13 +36,13 @@ def case(name, M, N, K, act=0, bias=False, residual=False, tn=False, split=1, cf
     line = f"{name:30s} {M}x{N}x{K}"
     ref = None
     for cfg in cfgs:
-        lib.kai0_gemm_set_cfg(cfg)
+        ops.GEMM_TUNING["tile_cfg"] = cfg
         fn = lambda: gemm(A, W, out, M=M, N=N, K=K, ldc=N, split_k=split, **lay, **kw)
         ms = timeit(fn)
         o = out.clone()
         if ref is None: ref = o
         line += f"  cfg{cfg} {2.0 * M * N * K / ms / 1e9:6.0f}{'' if torch.equal(o, ref) else '!'}"
-    lib.kai0_gemm_set_cfg(0)
+    ops.GEMM_TUNING["tile_cfg"] = 0
     print(line, flush=True)
 
 case("siglip fc1 (act 1)", 24576, 4304, 1152, act=1, bias=True)

@@ -35,7 +35,7 @@ def case(name, M, N, K, act=0, bias=False, residual=False):
     if residual: kw.update(residual=rnd(M, N), ldr=N)
     res = {}
     for mode in (0, 2):
-        lib.kai0_gemm_set_persist(mode)
+        ops.GEMM_TUNING["persist"] = 2 if mode == 2 else 1
         out = torch.empty(M, N, dtype=BF16, device=dev)
         pre = torch.empty(M, N, dtype=BF16, device=dev) if act in (2, 3, 6, 1) else None
         pre2 = torch.empty(M, N, dtype=BF16, device=dev) if act == 6 else None
@@ -47,7 +47,7 @@ def case(name, M, N, K, act=0, bias=False, residual=False):
         ms = timeit(fn)
         flops = 2.0 * M * N * K * (2 if act == 6 else 1)
         res[mode] = (ms, flops / ms / 1e9, out.clone(), None if pre is None else pre.clone(), None if pre2 is None else pre2.clone())
-    lib.kai0_gemm_set_persist(1)
+    ops.GEMM_TUNING["persist"] = 0
     same = torch.equal(res[0][2], res[2][2]) and all((a is None) or torch.equal(a, b) for a, b in zip(res[0][3:], res[2][3:]))
     print(f"{name:34s} {M}x{N}x{K} act {act}: plain {res[0][1]:7.1f} TF/s ({res[0][0]:.3f} ms)  persistent {res[2][1]:7.1f} TF/s ({res[2][0]:.3f} ms)  "
           f"{'bit-identical' if same else 'DIFFERENT'}  {100 * (res[2][1] / res[0][1] - 1):+.1f} %", flush=True)

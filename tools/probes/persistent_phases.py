@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kai0_amd import _lib  # noqa: E402
+from kai0_amd import ops  # noqa: E402
 from kai0_amd.ops import gemm  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -16,7 +17,7 @@ BF16 = torch.bfloat16
 lib = _lib.load()
 if not hasattr(lib, "kai0_debug_ps_trace"):
     raise SystemExit("build the library with KAI0_HIPCC_FLAGS=-DKAI0_PS_TRACE first")
-lib.kai0_gemm_set_persist(2)
+ops.GEMM_TUNING["persist"] = 2  # every eligible NT launch on the persistent kernel
 
 
 def rnd(*s, sc=1.0):
