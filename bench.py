@@ -212,12 +212,12 @@ class GemmTimer:
         return out
 
 
-def _oracle_full_depth(O):
-    """The full-depth, full-width oracle (fp32), built without the minutes of nn.init / seeded randn a 2.8 B-parameter CPU
+def _oracle_full_depth(O, vocab: int):
+    """The full-depth, full-width oracle (fp32), built without the minutes of nn.init / seeded randn a multi-billion-parameter CPU
     model costs: allocated on the meta device, materialised, and filled from one N(0, 0.02) block tiled over every matrix
-    (values only need to be of the right scale for a timing).  vocab 2048 (synthetic prompt ids < 2048): the 0.53 B-row
-    embedding table and the dead expert lm_head carry no FLOPs and are left out of the host's memory."""
-    cfg = O.OracleConfig(dtype="float32", vocab_size=2048)
+    (values only need to be of the right scale for a timing).  `vocab`: 257152 (the benchmarked model: the embedding table's 0.53 B
+    parameters take part in clip + AdamW) when the host has the memory, else 2048 (the table carries no FLOPs)."""
+    cfg = O.OracleConfig(dtype="float32", vocab_size=vocab)
     with torch.device("meta"):
         model = O.OraclePI0(cfg)
     model.to_empty(device="cpu")
@@ -253,7 +253,10 @@ def cpu_baseline(batch: int = 32):
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     t0 = time.time()
-    model, cfg = _oracle_full_depth(O)
+    # full vocabulary if the host has room: 4.14 B stored f32 parameters + gradients + two AdamW moments of the 3.35 B
+    # trained ones ~ 16.6 + 13.4 + 26.8 GB; otherwise the 2048-row table of the earlier rounds (stated in `vocab`)
+    vocab = 257152 if psutil.virtual_memory().available > (96 << 30) else 2048
+    model, cfg = _oracle_full_depth(O, vocab)
     init_s = time.time() - t0
     obs, actions, noise, t = O.synthetic_batch(cfg, 1, seed=0)
     times = []
@@ -297,13 +300,15 @@ def cpu_baseline(batch: int = 32):
         "cores": cores,
         "kind": "port",
         "vocab": int(cfg.vocab_size),
-        "vocab_note": "the oracle is timed at vocab 2048 (synthetic prompt ids < 2048): the 257152-row embedding table carries no FLOPs; its "
-                      "AdamW update (0.53 B of the 3.35 B trained parameters) is NOT in optimizer_s",
+        "vocab_note": ("full vocabulary: the 257152-row embedding table's gradient, clip and AdamW update (0.53 B of the 3.35 B trained parameters) are "
+                       "in fwd_bwd_s_per_sample / optimizer_s" if vocab == 257152 else
+                       "the oracle is timed at vocab 2048 (host memory): the 257152-row embedding table carries no FLOPs; its AdamW update "
+                       "(0.53 B of the 3.35 B trained parameters) is NOT in optimizer_s"),
         "fwd_bwd_s_per_sample": t_fb,
         "optimizer_s": t_opt,
         "init_s": init_s,
         "sample": f"fp32 oracle, full depth and width (18 joint + 27 SigLIP layers x 3 cameras, {n_all / 1e9:.2f} B parameters with "
-        f"gradients; vocab 2048): 1 sample forward+backward = {t_fb:.2f} s (best of {len(times)}: "
+        f"gradients; vocab {vocab}): 1 sample forward+backward = {t_fb:.2f} s (best of {len(times)}: "
         f"{', '.join(f'{x:.1f}' for x in times)}), clip_grad_norm_ + AdamW.step over "
         f"{'all' if n_sub == n_all else f'{n_sub / 1e9:.2f} B (scaled by count to all)'} parameters = {t_opt:.2f} s; "
         f"a batch-{batch} step = {batch} x {t_fb:.2f} + {t_opt:.2f} = {step_s:.1f} s; model construction {init_s:.1f} s not included",
@@ -399,6 +404,80 @@ def measure_latency(model, cfg, device, iters: int = 40):
     return res
 
 
+def roofline_object(timer, timer_dual, timer_steps: int, B: int, ms_per_step: float) -> dict:
+    """The `roofline` object of the JSON line from the GEMM timers (both schedules)."""
+    gemm_ms, gemm_flops, n_launch = timer.summarize()
+    # algorithmic flops of a launch = 2 M N K of that launch (no tile padding counted); summed over the launches
+    # of the measured steps and divided by their summed HIP-event durations
+    achieved = gemm_flops / 1e12 / (gemm_ms / 1e3)
+    # PMC counters cannot be read from inside this process: the per-launch HBM-side bytes come from the committed
+    # rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh -> profiles/gemm_traffic.json)
+    traffic = {}
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gemm_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+    return {
+        "bound": "mfma",
+        "kernel": "gemm_bf16_kernel (NT/NN/TN variants; every Linear, attention matmul, dgrad and wgrad)",
+        "achieved": achieved,
+        "peak": MFMA_BF16_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+        "traffic": traffic.get("bytes_per_launch"),
+        "traffic_unit": "HBM-side bytes per GEMM launch (fetch + write), rocprofv3 PMC; not re-measured by this run",
+        "traffic_measured_by_this_run": False,
+        "traffic_source": traffic.get("source"),
+        "traffic_commit": traffic.get("commit"),
+        "traffic_date": traffic.get("date"),
+        "launches_per_step": n_launch // timer_steps,
+        "avg_launch_ms": gemm_ms / n_launch,
+        "gemm_ms_per_step": gemm_ms / timer_steps,
+        "algorithmic_tflop_per_step": TRAIN_TFLOP_PER_SAMPLE * B,
+        "needed_tflop_per_step": TRAIN_TFLOP_NEEDED_PER_SAMPLE * B,
+        "gemm_tflop_per_step": gemm_flops / timer_steps / 1e12,
+        "timed": f"HIP events over {timer_steps} further identical steps right after the timed region, with the second "
+                 "(action-expert) stream off so that every launch owns the chip while it is timed",
+        "frac_timed_inside_timed_region": False,
+        "frac_timed_steps": timer_steps,
+        "frac_timed_expert_stream": False,
+        "headline_schedule": (lambda ms, fl, n: {
+            "frac": fl / 1e9 / ms / MFMA_BF16_PEAK_TFLOPS, "achieved": fl / 1e9 / ms, "gemm_ms_per_step": ms / timer_steps,
+            "launches_per_step": n // timer_steps,
+            "note": "the same HIP events over two further steps with the action expert's chain on its second stream, as in the timed "
+                    "region: overlapping launches are each charged the time they share, so this is a lower bound per launch"})(*timer_dual.summarize())
+        if timer_dual is not None else None,
+        "step_frac_of_mfma_peak": TRAIN_TFLOP_NEEDED_PER_SAMPLE * B / (ms_per_step / 1e3) / MFMA_BF16_PEAK_TFLOPS,
+        "step_frac_priced_on_tflop_per_sample": TRAIN_TFLOP_NEEDED_PER_SAMPLE,
+        "families": timer.families(B, timer_steps),
+        "targets": {"gemma_blocks_frac": 0.40, "vit_blocks_frac": 0.40},
+        "peak_note": "peak = the guide's dense bf16 figure at 2.4 GHz; under these launches the socket sits at its 1400 W cap with the "
+                     "shader clock at 1.8-2.1 GHz (profiles/r05_clock_power_under_gemm.txt, not re-measured by this run)",
+    }
+
+
+def rank_census(device, world: int, per_rank_ms: list) -> dict:
+    """Who took part, answered by the line itself: the world size RCCL reports, one all_gather of the ranks' device
+    identities (uuid, else PCI bus id) and host names, and the per-rank step time of the timed region."""
+    import socket
+
+    props = torch.cuda.get_device_properties(device)
+    ident = str(getattr(props, "uuid", "") or "") or f"pci:{getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+    mine = {"rank": int(os.environ.get("RANK", "0")), "local_rank": device.index, "device": ident, "name": props.name, "host": socket.gethostname(),
+            "gcn_arch": getattr(props, "gcnArchName", "")}  # fmt: skip
+    seen = [mine]
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+    return {
+        "rccl_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+        "backend": dist.get_backend() if dist.is_initialized() else None,
+        "distinct_devices": len({(r["host"], r["device"]) for r in seen}),
+        "devices": seen,
+        "ms_per_step_per_rank": per_rank_ms,
+        "ms_per_step_spread": max(per_rank_ms) - min(per_rank_ms),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,13 +541,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:  # max over ranks, taken NOW: everything below is extra and must not be able to lose the headline
+        every = [torch.zeros_like(el) for _ in range(world)]
+        dist.all_gather(every, el)  # (the spread over ranks goes into the line: a straggler GPU shows up by itself)
+        per_rank_ms = [float(t) / args.steps * 1e3 for t in every]
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el)
+    ranks = rank_census(device, world, per_rank_ms)
     # Roofline of the dominant kernel: HIP events around every bf16 GEMM launch, over `timer_steps` further identical steps
     # right after the timed region (every rank steps, rank 0 measures).  Inside the timed region the 2 x 1417 event
     # records per step cost ~10 ms (1.7 %) and, at N > 1, would make rank 0 the straggler the max-over-ranks reports.
-    timer = None
+    timer = timer_dual = None
     timer_steps = 2
     if not args.no_gemm_timing:
         from kai0_amd import model as _model
@@ -486,6 +570,18 @@ def main():
         if timer is not None:
             timer.uninstall()
         _model.set_expert_stream(dual_was)
+        # ... and the HEADLINE schedule's own figure: the same events with the expert stream back on.  Launches that share
+        # the chip are each charged the time they overlap, so this fraction is a lower bound of what the launches achieve; it is the one
+        # that belongs to the timed region's schedule.
+        if dual_was:
+            if rank == 0:
+                timer_dual = GemmTimer()
+                timer_dual.install()
+            for _ in range(timer_steps):
+                trainer.train_step(obs, actions)
+            barrier()
+            if timer_dual is not None:
+                timer_dual.uninstall()
     # N > 1: what the collectives cost the compute stream.  Two further steps with the engine's wait bookkeeping on (events around
     # every place where the compute stream waits for a gather / reduce-scatter / the norm all-reduce, kai0_amd.sharded): per rank,
     # the ms per step the chip sat in those waits, i.e. the communication that overlap did NOT hide.  Outside the timed region for the
@@ -546,15 +642,28 @@ def main():
                     "config": {"workload": "pi0.5 full fine-tune bf16, batch 32 per MI355X, 3-cam 224x224 (BASELINE.json configs[1])",
                                "global_batch": B * world, "seq_len": 968 + 50, "parallelism": f"dp{world} ({headline_mode})", "final_loss": float(loss)},
                     "comm": comm,
+                    "ranks": ranks,
+                    "truncated": True,  # same schema as the full line minus the extras that had not been computed yet
                     "note": f"the extra measurement of the {other_mode} partition did not finish within the watchdog's limit and was abandoned; "
                             "the headline above was complete before it started",
                 }  # fmt: skip
+                if timer is not None:
+                    try:
+                        line["roofline"] = roofline_object(timer, timer_dual, timer_steps, B, elapsed / args.steps * 1e3)
+                    except Exception as e:  # noqa: BLE001 - the headline must go out whatever the extras do
+                        line["roofline_error"] = repr(e)[:200]
                 print(json.dumps(line), flush=True)
             os._exit(0)
 
-        watchdog = threading.Timer(float(os.environ.get("KAI0_BENCH_WATCHDOG_S", "420")), give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        def arm(seconds: float):
+            t = threading.Timer(seconds, give_up)
+            t.daemon = True
+            t.start()
+            return t
+
+        #  the rebuild of the 3.6 B-parameter model gets its own allowance; the measurement's clock starts after it
+        limit = float(os.environ.get("KAI0_BENCH_WATCHDOG_S", "420"))
+        watchdog = arm(limit + 240.0)
         try:
             if os.environ.get("KAI0_BENCH_TEST_HANG") == "1":  # (tests the watchdog: tools/gpu_tests.sh does not set it)
                 time.sleep(10**6)
@@ -566,6 +675,8 @@ def main():
             trainer = Trainer(model, world_size=world, rank=rank, peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000,
                               end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0, mode=other_mode)  # fmt: skip
             eng = trainer.engine
+            watchdog.cancel()
+            watchdog = arm(limit)  # model rebuilt: the measurement itself has `limit` seconds
             for _ in range(2):
                 trainer.train_step(obs, actions)
             eng.comm_profile = True
@@ -654,50 +765,13 @@ def main():
             },
         }
         if timer is not None:
-            gemm_ms, gemm_flops, n_launch = timer.summarize()
-            # algorithmic flops of a launch = 2 M N K of that launch (no tile padding counted); summed over the launches
-            # of the measured steps and divided by their summed HIP-event durations
-            achieved = gemm_flops / 1e12 / (gemm_ms / 1e3)
-            # PMC counters cannot be read from inside this process: the per-launch HBM-side bytes come from the committed
-            # rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh -> profiles/gemm_traffic.json)
-            traffic = {}
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gemm_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath))
-            out["roofline"] = {
-                "bound": "mfma",
-                "kernel": "gemm_bf16_kernel (NT/NN/TN variants; every Linear, attention matmul, dgrad and wgrad)",
-                "achieved": achieved,
-                "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": traffic.get("bytes_per_launch"),
-                "traffic_unit": "HBM-side bytes per GEMM launch (fetch + write), rocprofv3 PMC; not re-measured by this run",
-                "traffic_measured_by_this_run": False,
-                "traffic_source": traffic.get("source"),
-                "launches_per_step": n_launch // timer_steps,
-                "avg_launch_ms": gemm_ms / n_launch,
-                "gemm_ms_per_step": gemm_ms / timer_steps,
-                "algorithmic_tflop_per_step": TRAIN_TFLOP_PER_SAMPLE * B,
-                "needed_tflop_per_step": TRAIN_TFLOP_NEEDED_PER_SAMPLE * B,
-                "gemm_tflop_per_step": gemm_flops / timer_steps / 1e12,
-                "timed": f"HIP events over {timer_steps} further identical steps right after the timed region, with the second "
-                         "(action-expert) stream off so that every launch owns the chip while it is timed",
-                "frac_timed_inside_timed_region": False,
-                "frac_timed_steps": timer_steps,
-                "frac_timed_expert_stream": False,
-                "step_frac_of_mfma_peak": TRAIN_TFLOP_NEEDED_PER_SAMPLE * B / (ms_per_step / 1e3) / MFMA_BF16_PEAK_TFLOPS,
-                "step_frac_priced_on_tflop_per_sample": TRAIN_TFLOP_NEEDED_PER_SAMPLE,
-                "families": timer.families(B, timer_steps),
-                "targets": {"gemma_blocks_frac": 0.40, "vit_blocks_frac": 0.40},
-                "peak_note": "peak = the guide's dense bf16 figure at 2.4 GHz; under these launches the socket sits at its 1400 W cap with the "
-                             "shader clock at 1.8-2.1 GHz (profiles/r05_clock_power_under_gemm.txt, not re-measured by this run)",
-            }
+            out["roofline"] = roofline_object(timer, timer_dual, timer_steps, B, ms_per_step)
             if os.environ.get("KAI0_GEMM_BREAKDOWN"):
                 os.makedirs("gpurun_out", exist_ok=True)
                 json.dump(timer.breakdown(), open("gpurun_out/gemm_breakdown.json", "w"), indent=0)
         if comm is not None:
             out["comm"] = comm
+        out["ranks"] = ranks
         if trimmed is not None:
             out["trimmed_prompt"] = trimmed
         if world == 1 and not args.no_latency:

@@ -281,7 +281,7 @@ __device__ __forceinline__ void lds_barrier() {
 //   previous occupant died earliest, with counted waits (never vmcnt(0) inside the loop).  1: pieces issued after the phase's
 //   fragment reads; 2: pieces issued in the middle of the phase's MFMAs.
 template <bool A_KC, bool B_KC, int WM, int WN, int MT, int NT, bool PP, int NS = 2, int BKT = 64, int SCH = 0>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, ((WM * WN * 64) / 256) * ((MT == 8 && WM * WN == 4) ? 2 : 1)) void gemm_bf16_kernel(const GemmArgs p) {  // (256 x 128 on four waves: two blocks per CU)
     static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule: two 4-wave groups");
     static_assert(SCH == 0 || (SCH == 1 && PP && NS == 2 && BKT == 64 && MT == 8 && NT == 4) || (SCH == 3 && PP && NS == 4), "schedules: 0 plain / two-buffer ping-pong, 1 quadrant (256x256x64), 3 ring (256x256x32)");
     static_assert(!(PP && NS == 4) || SCH == 3, "the ring runs with every DMA piece between the MFMA rows");
@@ -810,9 +810,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    // wave-private slab: f32 [64][64] at smem + wave*16 KiB, filled MT/4 times (64 rows of the wave's sub-tile each).
+    // wave-private slab: f32 [64][64] at smem + wave*16 KiB (8-wave 128 x 128 tile: [32][64], 8 KiB), filled MT/4 times (64 rows of the wave's sub-tile each).
     // C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg.
-    float* slab = reinterpret_cast<float*>(smem + wave * 16384);
+    float* slab = reinterpret_cast<float*>(smem + wave * (AH * 4096));  // (f32 [AH * 16][64])
     const int64_t cz = z1 * p.sC1 + z2 * p.sC2;
     const int64_t rz = z1 * p.sR1 + z2 * p.sR2;
     const int64_t vz = z1 * p.rv_s1 + z2 * p.rv_s2;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
                              p.cmap.rpb == 0 && (N_ALIGNED8(p.N));
     auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
-        if constexpr (MT == 4 && WM == 2 && WN == 2 && A_KC && B_KC) if (p.act == 7) {
+        if constexpr (((MT == 4 && WM == 2) || (MT == 2 && WM == 4)) && WN == 2 && A_KC && B_KC) if (p.act == 7) {
             // RoPE epilogue (kai0hip.h act 7): the tile's columns are [64 first-half columns of a head | their 64 partners] (the caller
             // permuted B's rows), i.e. the partner of this wave's column c is column c of the OTHER wave of its tile row (wave ^ 1).
             // Accumulators -> the wave-private slabs, block barrier, then every lane reads its 8 columns from its own slab and the
@@ -852,27 +852,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void gemm_bf16_
             const int fi = ((n0 >> 7) & 1) * 64 + (lane & 7) * 8;                // frequency index of the lane's 8 columns
             const int rcol = rot ? (n0 >> 8) * 256 + wn * 128 + fi : n0 + wn * 64 + (lane & 7) * 8;   // REAL column
             const int rbase = row_base(h) + (lane >> 3);
-            bf16x8 cs[8], sn[8];
+            bf16x8 cs[AH * 2], sn[AH * 2];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < AH * 2; ++it) {
                 const int64_t tr = (int64_t)min(rbase + it * 8, p.M - 1) * p.rope_half + fi;  // (clamped: unconditional loads)
                 cs[it] = *reinterpret_cast<const bf16x8*>(p.rope_cos + (rot ? tr : 0));
                 sn[it] = *reinterpret_cast<const bf16x8*>(p.rope_sin + (rot ? tr : 0));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < AH; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * 64 + j * 16 + l15] = acc[i][j][r];
             lds_barrier();
-            const float* pslab = reinterpret_cast<const float*>(smem + (wave ^ 1) * 16384);
+            const float* pslab = reinterpret_cast<const float*>(smem + (wave ^ 1) * (AH * 4096));
             int si = 0;
             if (p.nseg > 1 && rcol >= p.seg_begin[1]) si = 1;
             if (p.nseg > 2 && rcol >= p.seg_begin[2]) si = 2;
             const bool rcol_ok = rcol < p.N;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < AH * 2; ++it) {
                 const int lr = it * 8 + (lane >> 3);
                 const int row = rbase + it * 8;
                 const int so = lr * 64 + (lane & 7) * 8;
@@ -2051,9 +2051,9 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     const bool deep = forced ? forced == 2 : (small_blocks <= 256 && p.k_chunk >= 256);
     // 128 x 128 on EIGHT waves (4 x 2 wave tiles of 32 x 64; round 6): with at most one block per CU the four-wave loop has one wave per
     // SIMD, so a K-tile is that wave's 8 LDS-DMA issues + 16 fragment reads + 32 MFMAs one after the other (~1470 clocks for 544 of MFMA);
-    // two waves per SIMD let one wave's MFMAs run under the other's DMA issue and read latency.  K-contiguous operands, act 0 / 1 (the
+    // two waves per SIMD let one wave's MFMAs run under the other's DMA issue and read latency.  K-contiguous operands, act 0 / 1 / 7 (the
     // epilogues the narrower wave tile implements); kai0_gemm_desc.small_w8: 0 = this rule, 1 = never, 2 = every eligible 128 x 128 launch.
-    const bool w8_ok = !big && d->a_kc && d->b_kc && d->act <= 1 && (forced == 0 || forced == 3);
+    const bool w8_ok = !big && d->a_kc && d->b_kc && (d->act <= 1 || d->act == 7) && (forced == 0 || forced == 3);
     const bool w8 = w8_ok && (forced == 3 || d->small_w8 == 2 || (d->small_w8 == 0 && deep));
     // forced (kai0_gemm_desc.tile_cfg, A/B runs): 1 / 2 = 128x128 with 2 / 4 stages, 4 = 256x256 plain loop, 5 = 256x256
     // two-buffer ping-pong for every layout.  Measured (MLP shapes, random data): the 32-deep ring wins +21 % for the transpose-read
@@ -2099,8 +2099,12 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
         hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(nblk), dim3(512), LDS, s, p, ctr);
         return kai0_check_launch("kai0_gemm_bf16 (persistent)");
     }
+    // A/B configurations with TWO blocks per CU (round 6, VERDICT r5 #2 "two tiles in flight per CU": one block's epilogue under the other's
+    // K loop): 6 = the eight-wave 128 x 128 tile with two stages (64 KiB), 7 = 256 x 128 x 32 on four waves with three stages (72 KiB)
+    if (forced == 6) rc = launch_cfg<4, 2, 2, 4, false, 2>(d, p, batch, s);
+    else if (forced == 7) rc = launch_cfg<2, 2, 8, 4, false, 3, 32>(d, p, batch, s);
     // TN: ring with every DMA piece (and its offset arithmetic) between the MFMA rows
-    if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32, 3>(d, p, batch, s);
+    else if (big && ring) rc = launch_cfg<2, 4, 8, 4, true, 4, 32, 3>(d, p, batch, s);
     else if (big && !pp) rc = launch_cfg<2, 4, 8, 4, false>(d, p, batch, s);
     else if (big && d->b_kc && forced != 5) rc = launch_cfg<2, 4, 8, 4, true, 2, 64, 1>(d, p, batch, s);  // NT: quadrant schedule
     else if (big) rc = launch_cfg<2, 4, 8, 4, true>(d, p, batch, s);

@@ -712,6 +712,12 @@ class PI0Pytorch(nn.Module):
             # ... the other prompt-length buckets' engines too: their own stamps still equal their reference (they have not run since
             # the edit), so `compatible()` would accept them and the next request in their bucket would compute from old weights
             self.__dict__.pop("_engine_lru", None)
+        if eng is not None and eng.shape_matches(*key):
+            # the common serving case: same request shape as the last call.  The captured chunk is queued BEFORE the weights are checked
+            # (0.13 ms of host work that would otherwise stand in front of every chunk); a failed check falls through to the rebuild
+            out = eng.replay_then_verify(images, img_masks, lang_tokens, lang_masks, noise.to(F32), num_steps)
+            if out is not None:
+                return out
         if eng is None or not eng.compatible(*key):
             lru = self.__dict__.setdefault("_engine_lru", {})
             eng = lru.pop(key, None)

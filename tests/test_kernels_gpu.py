@@ -213,8 +213,9 @@ def test_gemm_batch_strides_may_be_negative_or_span_two_allocations(ops):
                  sA=(Bn * K * M, K * M), sB=(dist + 4, K * N), sC=(Bn * M * N, M * N))
 
 
+@pytest.mark.parametrize("w8", [1, 2])  # the four-wave and the eight-wave 128 x 128 tile (kai0_gemm_desc.small_w8)
 @pytest.mark.parametrize("B,P,S_ld,T", [(1, 968, 1024, 200), (2, 136, 160, 40)])
-def test_gemm_rope_epilogue_is_bit_identical_to_gemm_then_rope(ops, B, P, S_ld, T):
+def test_gemm_rope_epilogue_is_bit_identical_to_gemm_then_rope(ops, B, P, S_ld, T, w8):
     """act 7 (kai0hip.h): the stacked q | k | v projection of the B = 1 prefix pass with the rotation in its epilogue — weight rows
     permuted so that a rotation's partners meet in one 128-column tile, output routed to the padded q buffer and the K / V caches at
     the REAL columns — against the same GEMM followed by kai0_rope_inplace2: bit for bit, padding rows untouched."""
@@ -237,8 +238,9 @@ def test_gemm_rope_epilogue_is_bit_identical_to_gemm_then_rope(ops, B, P, S_ld, 
     q1, k1, v1 = bufs()
     perm = ops.rope_permutation(NQ + 2 * HD, NQ + HD).to(dev())
     cos, sin = ops.rope_table(pos.reshape(-1), inv_freq)
-    ops.gemm(x, w[perm].contiguous(), q1, M=M, N=NQ + 2 * HD, K=D, lda=D, ldb=D, ldc=NQ, c_map=(P, S_ld, 0), segs=segs(q1, k1, v1), act=7,
-             rope=(cos.to(BF16), sin.to(BF16), HD // 2, NQ + HD))
+    with ops.gemm_tuning(small_w8=w8):
+        ops.gemm(x, w[perm].contiguous(), q1, M=M, N=NQ + 2 * HD, K=D, lda=D, ldb=D, ldc=NQ, c_map=(P, S_ld, 0), segs=segs(q1, k1, v1), act=7,
+                 rope=(cos.to(BF16), sin.to(BF16), HD // 2, NQ + HD))
     assert torch.equal(q1, q0) and torch.equal(k1, k0) and torch.equal(v1, v0)
     assert float(q1[:, P:].float().min()) == 3.0 and float(k1[:, P:].float().min()) == 3.0  # padding rows untouched
     ref = (x.float() @ w.float().t()).to(BF16).float().view(B, P, -1)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace stats of the bench command and of one action chunk, plus three PMC
 # passes over one training step.  Only small text summaries are kept (gpurun copies back <= 64 MiB).
+# usage (from the build container; the box has no .git):  gpurun -- "KAI0_COMMIT=$(git rev-parse --short HEAD) bash tools/collect_profiles.sh"
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/summary; rm -rf $OUT; mkdir -p $OUT

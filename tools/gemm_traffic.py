@@ -3,14 +3,16 @@ usage: gemm_traffic.py <fetch dir> <write dir> <out json>.  Per MI355X_MICROARCH
 FETCH_SIZE reports half the bytes of wide streaming reads (x2 applied here), WRITE_SIZE is taken as reported; Infinity-Cache
 hits are included (the counters sit on the L2's fabric side)."""
 import csv
+import datetime
 import json
+import os
 import sys
 
 
 def total(d, counter):
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(d + "/p_counter_collection.csv")):
-        if "gemm_bf16_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if ("gemm_bf16_kernel" in r["Kernel_Name"] or "gemm_nt_persistent_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
     return tot, len(disp)
@@ -20,6 +22,9 @@ f, nf = total(sys.argv[1], "FETCH_SIZE")
 w, nw = total(sys.argv[2], "WRITE_SIZE")
 out = {"bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0, "fetch_bytes_per_launch": 2.0 * f / nf * 1024.0,
        "write_bytes_per_launch": w / nw * 1024.0, "launches": nf,
+       # which code these counters belong to: the GPU box has no .git, so the caller passes the commit in (tools/collect_profiles.sh:
+       # `gpurun -- "KAI0_COMMIT=$(git rev-parse --short HEAD) bash tools/collect_profiles.sh"`); bench.py emits both as traffic_commit / traffic_date
+       "commit": os.environ.get("KAI0_COMMIT", "unknown"), "date": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 1; "
                  "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md), KiB -> bytes; tools/collect_profiles.sh"}  # fmt: skip
 json.dump(out, open(sys.argv[3], "w"), indent=1)
