@@ -460,6 +460,8 @@ def rank_census(device, world: int, per_rank_ms: list) -> dict:
     identities (uuid, else PCI bus id) and host names, and the per-rank step time of the timed region."""
     import socket
 
+    import torch.distributed as dist
+
     props = torch.cuda.get_device_properties(device)
     ident = str(getattr(props, "uuid", "") or "") or f"pci:{getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
     mine = {"rank": int(os.environ.get("RANK", "0")), "local_rank": device.index, "device": ident, "name": props.name, "host": socket.gethostname(),
@@ -548,7 +550,10 @@ def main():
         per_rank_ms = [float(t) / args.steps * 1e3 for t in every]
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el)
-    ranks = rank_census(device, world, per_rank_ms)
+    try:
+        ranks = rank_census(device, world, per_rank_ms)
+    except Exception as e:  # noqa: BLE001 - diagnostics must never cost the headline
+        ranks = {"error": f"{type(e).__name__}: {e}", "ms_per_step_per_rank": per_rank_ms}
     # Roofline of the dominant kernel: HIP events around every bf16 GEMM launch, over `timer_steps` further identical steps
     # right after the timed region (every rank steps, rank 0 measures).  Inside the timed region the 2 x 1417 event
     # records per step cost ~10 ms (1.7 %) and, at N > 1, would make rank 0 the straggler the max-over-ranks reports.

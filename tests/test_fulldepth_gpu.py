@@ -11,7 +11,7 @@ Tolerances: loss rel-L2 <= 1e-2; chunk rel-L2 <= 3e-3 and max|
 the fp32 oracle.  Gradients (round 4): BASELINE.md states no tolerance, so the bar is what the REFERENCE'S OWN bf16 choreography
 loses against fp32 — the bf16 oracle is run backward too and, per parameter, HIP-vs-fp32 must stay within 1.5 x (bf16-oracle-vs-fp32)
 + 2e-3 (and under the flat 5e-2 of the earlier rounds); both columns are written out.  The measured numbers go to
-gpurun_out/parity_r05_fulldepth.txt (committed under profiles/; round 4: profiles/parity_r04.txt) and gpurun_out/grad_table_fulldepth.txt.  Host cost on the 64-core
+gpurun_out/parity_fulldepth.txt (committed as profiles/parity_r06_fulldepth.txt; earlier rounds: parity_r03 / r04 / r05*.txt) and gpurun_out/grad_table_fulldepth.txt.  Host cost on the 64-core
 bench box: fp32 forward + backward ~25 s, bf16 forward + backward ~10 s, fp32 chunk ~12 s."""
 
 import os
@@ -27,7 +27,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 F32 = torch.float32
-REPORT = os.path.join("gpurun_out", "parity_r05_fulldepth.txt")
+REPORT = os.path.join("gpurun_out", "parity_fulldepth.txt")
 WITH_BF16_ORACLE = os.environ.get("KAI0_FULLDEPTH_BF16", "1") != "0"
 
 
