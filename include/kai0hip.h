@@ -299,9 +299,21 @@ int64_t kai0_attn_decode_workspace_bytes(int batch, int rows);
 int kai0_transpose_strided_bf16(const void* src, void* dst, int R, int C, int64_t src_ld, int64_t dst_ld, int batch,
                                 int64_t src_bs, int64_t dst_bs, kai0_stream_t stream);
 
-/* cos_out/sin_out[r][d] = bf16_round(cos/sin(inv_freq[d] * pos[r])) as f32, r < rows, d < half */
-int kai0_rope_table(const int32_t* pos, const float* inv_freq, float* cos_out, float* sin_out, int64_t rows, int half,
+/* cos_out/sin_out[r][d] = bf16_round(cos/sin(inv_freq[d] * pos[r])), r < rows, d < half; stored as f32 (out_bf16 = 0) or as bf16
+ * (out_bf16 = 1: the tables kai0_gemm_bf16's act 7 reads) — the same values either way */
+int kai0_rope_table(const int32_t* pos, const float* inv_freq, void* cos_out, void* sin_out, int64_t rows, int half, int out_bf16,
                     kai0_stream_t stream);
+/* Mask codes and position ids of one pi0.5 request in ONE launch (pi0_pytorch.py:52-81 make_att_2d_masks, :186-235 embed_prefix's
+ * pad / att masks, :237-314 embed_suffix's, :343 position_ids = cumsum(pad) - 1), for the sequence
+ *   [cam 0: n_img image tokens | ... | cam ncam-1 | T prompt tokens | Hs action tokens]:
+ * pad = the camera's mask for its image tokens, the prompt mask for prompt tokens, true for action tokens; att = 0 over the prefix
+ * and [1, 0, 0, ...] over the suffix, i.e. cumsum(att) = 0 / 1.  Outputs, int32 [B][S] (S = ncam n_img + T + Hs, row stride S):
+ *   qcode = pad ? cumsum(att) : -1,  kcode = pad ? cumsum(att) : INT_MAX  (token j visible from i  <=>  kcode[j] <= qcode[i]),
+ *   pos = cumsum(pad) - 1.
+ * img_masks: ncam device pointers (host array) to bool [B]; lang_mask bool [B][T] contiguous.  Integer logic: bit-exact against the
+ * torch restatement (kai0_amd.model.build_mask_codes).  ncam <= 8. */
+int kai0_prefix_codes(const void* const* img_masks, int ncam, const void* lang_mask, int B, int n_img, int T, int Hs, int32_t* qcode,
+                      int32_t* kcode, int32_t* pos, kai0_stream_t stream);
 
 /* f32 MFMA GEMM, fully strided: C[m,n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C).
  * split_k > 1 slices the contraction over grid.z into raw partial tiles workspace[split_k][M][N] (f32; size from

@@ -136,7 +136,8 @@ _PROTOS: dict[str, list] = {
     "kai0_attn_bwd_dq": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                          c_f, c_p],
     "kai0_transpose_strided_bf16": [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i64, c_i64, c_p],
-    "kai0_rope_table": [c_p, c_p, c_p, c_p, c_i64, c_i, c_p],
+    "kai0_rope_table": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
+    "kai0_prefix_codes": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "kai0_gemm_f32": [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i64, c_p],
     "kai0_linear_rows_f32": [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p],
     "kai0_rmsnorm_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p],

@@ -933,3 +933,63 @@ KAI0_API int kai0_euler_step(float* x, const float* v, float dt, int64_t n, kai0
     hipLaunchKernelGGL(euler_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_(stream), x, v, dt, n);
     return kai0_check_launch("kai0_euler_step");
 }
+
+// ---- mask codes + position ids of one request, one launch (kai0hip.h kai0_prefix_codes) -----------------------------------------
+namespace {
+struct CodesArgs {
+    const uint8_t* img[8];
+    const uint8_t* lang;
+    int ncam, n_img, T, Hs;
+};
+__global__ __launch_bounds__(256) void prefix_codes_kernel(const CodesArgs a, int32_t* __restrict__ qcode, int32_t* __restrict__ kcode,
+                                                           int32_t* __restrict__ pos) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P_img = a.ncam * a.n_img, P = P_img + a.T, S = P + a.Hs;
+    const int per = (S + 255) / 256, j0 = tid * per, j1 = min(S, j0 + per);
+    auto padded = [&](int j) -> bool {
+        if (j < P_img) return a.img[j / a.n_img][b] != 0;
+        if (j < P) return a.lang[(int64_t)b * a.T + (j - P_img)] != 0;
+        return true;
+    };
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) cnt += padded(j) ? 1 : 0;
+    // exclusive scan of the threads' counts: within the wave by shuffles, across the four waves through LDS
+    int inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - cnt;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int run = base;
+    for (int j = j0; j < j1; ++j) {
+        const bool pd = padded(j);
+        run += pd ? 1 : 0;
+        const int cum = j >= P ? 1 : 0;
+        const int64_t o = (int64_t)b * S + j;
+        qcode[o] = pd ? cum : -1;
+        kcode[o] = pd ? cum : INT_MAX;
+        pos[o] = run - 1;
+    }
+}
+}  // namespace
+
+KAI0_API int kai0_prefix_codes(const void* const* img_masks, int ncam, const void* lang_mask, int B, int n_img, int T, int Hs,
+                               int32_t* qcode, int32_t* kcode, int32_t* pos, kai0_stream_t stream) {
+    KAI0_REQUIRE(img_masks && lang_mask && qcode && kcode && pos, "kai0_prefix_codes: null operand");
+    KAI0_REQUIRE(ncam >= 1 && ncam <= 8 && n_img >= 1 && T >= 0 && Hs >= 0 && B >= 1, "kai0_prefix_codes: ncam=%d n_img=%d T=%d Hs=%d B=%d",
+                 ncam, n_img, T, Hs, B);
+    CodesArgs a{};
+    for (int c = 0; c < ncam; ++c) {
+        KAI0_REQUIRE(img_masks[c] != nullptr, "kai0_prefix_codes: null camera mask %d", c);
+        a.img[c] = (const uint8_t*)img_masks[c];
+    }
+    a.lang = (const uint8_t*)lang_mask;
+    a.ncam = ncam; a.n_img = n_img; a.T = T; a.Hs = Hs;
+    hipLaunchKernelGGL(prefix_codes_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, qcode, kcode, pos);
+    return kai0_check_launch("kai0_prefix_codes");
+}

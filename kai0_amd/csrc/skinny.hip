@@ -600,16 +600,22 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny2_kernel(const SkinnyArgs p)
     SK2_STAMP(7);  // epilogue stores issued
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restrict__ pos, const float* __restrict__ inv_freq,
-                                                         float* __restrict__ cos_out, float* __restrict__ sin_out,
+                                                         void* __restrict__ cos_out, void* __restrict__ sin_out,
                                                          int64_t n, int half) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const int64_t r = t / half;
     const int d = (int)(t - r * half);
     const float ang = inv_freq[d] * (float)pos[r];
-    cos_out[t] = rbf(cosf(ang));
-    sin_out[t] = rbf(sinf(ang));
+    if constexpr (BF) {  // the same bf16-rounded values, stored as bf16 (what the RoPE epilogue of kai0_gemm_bf16 reads)
+        reinterpret_cast<bf16_t*>(cos_out)[t] = f2bf(cosf(ang));
+        reinterpret_cast<bf16_t*>(sin_out)[t] = f2bf(sinf(ang));
+    } else {
+        reinterpret_cast<float*>(cos_out)[t] = rbf(cosf(ang));
+        reinterpret_cast<float*>(sin_out)[t] = rbf(sinf(ang));
+    }
 }
 
 }  // namespace
@@ -793,11 +799,15 @@ KAI0_API int kai0_gemm_skinny_bf16(const kai0_skinny_desc* d, kai0_stream_t stre
     return kai0_check_launch("kai0_gemm_skinny_bf16");
 }
 
-KAI0_API int kai0_rope_table(const int32_t* pos, const float* inv_freq, float* cos_out, float* sin_out, int64_t rows,
-                             int half, kai0_stream_t stream) {
+KAI0_API int kai0_rope_table(const int32_t* pos, const float* inv_freq, void* cos_out, void* sin_out, int64_t rows,
+                             int half, int out_bf16, kai0_stream_t stream) {
     const int64_t n = rows * half;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, inv_freq,
-                       cos_out, sin_out, n, half);
+    if (out_bf16)
+        hipLaunchKernelGGL(rope_table_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, inv_freq,
+                           cos_out, sin_out, n, half);
+    else
+        hipLaunchKernelGGL(rope_table_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, inv_freq,
+                           cos_out, sin_out, n, half);
     return kai0_check_launch("kai0_rope_table");
 }

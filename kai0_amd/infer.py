@@ -212,7 +212,7 @@ class InferenceEngine:
             for l in range(self.L - 1):
                 self.lm_wqkv[l] = self.lm_wqkv[l][perm].contiguous()
 
-    def _lin(self, x, w, *, bias=None, residual=None, act=0, split=None, aux1=None, norm=None):
+    def _lin(self, x, w, *, bias=None, residual=None, act=0, split=None, aux1=None, norm=None, out=None):
         """flat Linear for the prefix / SigLIP passes: launches matter more than occupancy here, so the contraction is
         only split when there are fewer than ~100 output tiles.
         norm = (kind, weight, bias | None, eps): the norm that reads this Linear's output — returns (out, norm(out)); when the
@@ -222,7 +222,8 @@ class InferenceEngine:
         if split is None:
             tiles = ((M + 127) // 128) * ((N + 127) // 128)
             split = _B1_SPLITS.get((M, N, K)) or (1 if tiles >= 100 else pick_split_k(M, N, K))
-        out = torch.empty((M, N), dtype=BF16, device=self.dev)
+        if out is None:
+            out = torch.empty((M, N), dtype=BF16, device=self.dev)
         fused = None
         if norm is not None and self.fuse_norm and split > 1 and N <= 2048 and N % 8 == 0 and act == 0:
             kind, nw, nb, neps = norm
@@ -236,7 +237,7 @@ class InferenceEngine:
         kind, nw, nb, neps = norm
         return out, (ops.rmsnorm(out, nw, neps) if kind == 1 else ops.layernorm(out, nw, nb, neps))
 
-    def _siglip(self, image):
+    def _siglip(self, image, out=None):
         """SigLIP tower for inference (modeling_siglip.py:271-281,325-460,756-778): stacked q|k|v projection, attention
         straight off the stacked buffer, no probabilities written, GELU / bias / residual in the GEMM epilogues."""
         pe = self.pe
@@ -271,23 +272,30 @@ class InferenceEngine:
             x, h = self._lin(f, layer.mlp.fc2.weight, bias=layer.mlp.fc2.bias, residual=x, norm=(2, nxt.weight, nxt.bias, nxt.eps))
         x = h  # = post_layernorm(x)
         proj = pe.paligemma.model.multi_modal_projector.linear
-        return self._lin(x, proj.weight, bias=proj.bias).view(n, S, -1)
+        return self._lin(x, proj.weight, bias=proj.bias, out=out).view(n, S, -1)  # (`out`: the prefix buffer's image rows, B = 1)
 
     def _embed_prefix(self, images, img_masks, lang_tokens, lang_masks):
-        """PI0Pytorch.embed_prefix (pi0_pytorch.py:186-235) over the inference SigLIP tower."""
-        from .model import PrefixAssembleFn
-
+        """PI0Pytorch.embed_prefix (pi0_pytorch.py:186-235) over the inference SigLIP tower -> the flat prefix [B * P, D].  Round 6: no
+        assembly copies — the prompt embedding is gathered straight into its rows of the prefix buffer (kai0_embed_gather's row offset /
+        strides) and, at B = 1 (where camera-major == sequence order), the projector GEMM writes the image rows there too; the pad / att
+        masks are not materialised (kai0_prefix_codes, `_prefix_pass`)."""
         pe = self.pe
         B, ncam = lang_tokens.shape[0], len(images)
-        feats = self._siglip(torch.cat(images, dim=0))
-        n_img, D = feats.shape[1], feats.shape[2]
-        lang = ops.embed(pe.paligemma.model.language_model.embed_tokens.weight, lang_tokens, ops.sqrt_scale(D))
-        T = lang_tokens.shape[1]
+        n_img, D, T = self.n_img, self.Dp, lang_tokens.shape[1]
         P = ncam * n_img + T
-        embs = PrefixAssembleFn.apply(feats.reshape(ncam * B * n_img, D), lang, B, ncam, n_img, T)
-        pad = torch.cat([m[:, None].expand(B, n_img) for m in img_masks] + [lang_masks.to(torch.bool)], dim=1)
-        att = torch.zeros((B, P), dtype=torch.bool, device=pad.device)
-        return embs.view(B, P, D), pad, att
+        embs = torch.empty((B * P, D), dtype=BF16, device=self.dev)
+        direct = B == 1
+        feats = self._siglip(torch.cat(images, dim=0), out=embs[: ncam * n_img] if direct else None)
+        if feats.shape[2] != D:
+            raise ValueError(f"prefix assembly: projector width {feats.shape[2]} != PaliGemma width {D}")
+        tok = lang_tokens.to(torch.int64).contiguous() if lang_tokens.dtype != torch.int64 else lang_tokens.contiguous()
+        table = pe.paligemma.model.language_model.embed_tokens.weight
+        _lib.call("kai0_embed_gather", table.data_ptr(), tok.data_ptr(), embs.data_ptr(), B, T, D, ops.sqrt_scale(D), P * D, ncam * n_img, D,
+                  ops._stream())  # fmt: skip
+        if not direct:
+            for c in range(ncam):
+                ops._copy_rows(feats.reshape(ncam * B * n_img, D)[c * B * n_img :], embs, B, n_img, D, n_img * D, 0, D, P * D, c * n_img, D)
+        return embs.view(B, P, D)
 
     def _build_fast(self):
         ex = self.pe.gemma_expert.model
@@ -365,14 +373,10 @@ class InferenceEngine:
     def _prefix_pass(self, images, img_masks, lang_tokens, lang_masks):
         model, pe = self.model, self.pe
         B, P, Hs = self.B, self.P, self.Hs
-        prefix, ppad, patt = self._embed_prefix(images, img_masks, lang_tokens, lang_masks)
-        dev = prefix.device
-        spad = torch.ones((B, Hs), dtype=torch.bool, device=dev)
-        satt = torch.zeros((B, Hs), dtype=torch.bool, device=dev)
-        satt[:, 0] = True
-        from .model import build_mask_codes
-
-        qcode, kcode, pos = build_mask_codes(torch.cat([ppad, spad], dim=1), torch.cat([patt, satt], dim=1))
+        prefix = self._embed_prefix(images, img_masks, lang_tokens, lang_masks)
+        # mask codes and position ids of the whole request (prefix + action tokens) in one launch: what build_mask_codes makes of
+        # embed_prefix's / embed_suffix's pad and att masks, bit for bit (tests/test_kernels_gpu.py::test_prefix_codes_...)
+        qcode, kcode, pos = ops.prefix_codes([m.to(torch.bool) for m in img_masks], lang_masks.to(torch.bool), self.n_img, Hs)
         self.qcode, self.kcode, self.pos = qcode, kcode, pos
         self.pos_prefix = pos[:, :P].contiguous()
         self.pos_suffix = pos[:, P:].contiguous()
@@ -386,8 +390,7 @@ class InferenceEngine:
         lm_layers = list(lm.layers)
         hp = ops.rmsnorm(xp, lm_layers[0].input_layernorm.weight, lm_layers[0].input_layernorm.eps)
         if self.fuse_rope:  # the rotation's tables for the prefix rows of this request, once per chunk (bf16: the values are bf16-rounded)
-            cs, sn = ops.rope_table(self.pos_prefix.reshape(-1), inv_freq)
-            rope_cos, rope_sin = ops.cast(cs, BF16), ops.cast(sn, BF16)
+            rope_cos, rope_sin = ops.rope_table(self.pos_prefix.reshape(-1), inv_freq, bf16=True)
         for l, layer in enumerate(lm_layers):
             at = layer.self_attn
             if l == self.L - 1:

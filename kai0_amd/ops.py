@@ -288,16 +288,34 @@ def rope_permutation(n_total: int, n_rope_end: int, half: int = 128) -> torch.Te
     return torch.where(pc < n_rope_end, real, pc)
 
 
-def rope_table(pos, inv_freq):
-    """-> (cos, sin) f32 [rows, HD/2], bf16-rounded values, rows = pos.numel() (pos int32)."""
+def rope_table(pos, inv_freq, bf16: bool = False):
+    """-> (cos, sin) [rows, HD/2], bf16-rounded values, rows = pos.numel() (pos int32); stored as f32, or as bf16 with `bf16`."""
     pos = pos.contiguous()
     if pos.dtype != torch.int32:
         raise TypeError("rope_table: pos must be int32")
     rows, half = pos.numel(), inv_freq.numel()
-    cos = torch.empty((rows, half), dtype=F32, device=pos.device)
-    sin = torch.empty((rows, half), dtype=F32, device=pos.device)
-    _lib.call("kai0_rope_table", pos.data_ptr(), inv_freq.data_ptr(), cos.data_ptr(), sin.data_ptr(), rows, half, _stream())
+    cos = torch.empty((rows, half), dtype=BF16 if bf16 else F32, device=pos.device)
+    sin = torch.empty((rows, half), dtype=BF16 if bf16 else F32, device=pos.device)
+    _lib.call("kai0_rope_table", pos.data_ptr(), inv_freq.data_ptr(), cos.data_ptr(), sin.data_ptr(), rows, half, int(bf16), _stream())
     return cos, sin
+
+
+def prefix_codes(img_masks, lang_mask, n_img: int, Hs: int):
+    """kai0_prefix_codes: (qcode, kcode, pos) int32 [B, ncam n_img + T + Hs] of one pi0.5 request from its camera masks (bool [B] each) and
+    prompt mask (bool [B, T]) in one launch — bit for bit `model.build_mask_codes` on embed_prefix's / embed_suffix's pad and att masks."""
+    B, T = lang_mask.shape
+    ms = [m.contiguous() for m in img_masks]
+    lm = lang_mask.contiguous()
+    for m in (*ms, lm):
+        if m.dtype != torch.bool or not m.is_cuda:
+            raise TypeError("prefix_codes: bool CUDA (HIP) masks expected")
+    if any(m.shape != (B,) for m in ms):
+        raise ValueError("prefix_codes: camera masks must be [B]")
+    S = len(ms) * n_img + T + Hs
+    q, k, p = (torch.empty((B, S), dtype=torch.int32, device=lm.device) for _ in range(3))
+    ptrs = (C.c_void_p * len(ms))(*[m.data_ptr() for m in ms])
+    _lib.call("kai0_prefix_codes", C.addressof(ptrs), len(ms), lm.data_ptr(), B, n_img, T, Hs, q.data_ptr(), k.data_ptr(), p.data_ptr(), _stream())
+    return q, k, p
 
 
 _WS: dict = {}

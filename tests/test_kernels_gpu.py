@@ -971,6 +971,38 @@ def test_skinny_geglu(ops):
     assert_close_bf16(h, ref.float(), what="skinny geglu", tol=1e-2)
 
 
+@pytest.mark.parametrize("B,ncam,n_img,T,Hs", [(1, 3, 256, 200, 50), (3, 2, 16, 24, 5), (2, 1, 7, 1, 1), (4, 6, 256, 200, 50)])
+def test_prefix_codes_equal_build_mask_codes_bit_for_bit(ops, B, ncam, n_img, T, Hs):
+    """kai0_prefix_codes (one launch) against the torch restatement of make_att_2d_masks' inputs (pi0_pytorch.py:52-81,186-235,237-314,343):
+    pad = [camera masks expanded | prompt mask | ones], att = [0 ... 0 | 1 0 ... 0] -> build_mask_codes.  Integer logic: equal bits,
+    with masked-out cameras, ragged prompt masks (holes included) and rows whose every prompt token is padding."""
+    from kai0_amd.model import build_mask_codes
+
+    g = torch.Generator().manual_seed(B * 131 + ncam)
+    img_masks = [(torch.rand(B, generator=g) > 0.3).to(dev()) for _ in range(ncam)]
+    lang = (torch.rand(B, T, generator=g) > 0.35)
+    lang[0] = torch.arange(T) < max(1, T // 2)  # the usual form: valid tokens first
+    if B > 1:
+        lang[1] = False
+    lang = lang.to(dev())
+    P = ncam * n_img + T
+    pad = torch.cat([m[:, None].expand(B, n_img) for m in img_masks] + [lang, torch.ones(B, Hs, dtype=torch.bool, device=dev())], dim=1)
+    att = torch.zeros(B, P + Hs, dtype=torch.bool, device=dev())
+    att[:, P] = True
+    want = build_mask_codes(pad, att)
+    got = ops.prefix_codes(img_masks, lang, n_img, Hs)
+    for a, b, name in zip(got, want, ("qcode", "kcode", "pos")):
+        assert a.dtype == torch.int32 and torch.equal(a, b), name
+
+
+def test_rope_table_bf16_output_holds_the_same_values(ops):
+    pos = torch.randint(0, 1100, (977,), dtype=torch.int32, device=dev())
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, 256, 2).float() / 256))).to(BF16).float().to(dev())
+    c32, s32 = ops.rope_table(pos, inv_freq)
+    c16, s16 = ops.rope_table(pos, inv_freq, bf16=True)
+    assert c16.dtype == BF16 and torch.equal(c16.float(), c32) and torch.equal(s16.float(), s32)
+
+
 @pytest.mark.parametrize("B,Hs,P", [(1, 50, 968), (2, 50, 200), (1, 3, 29)])
 def test_attn_decode_matches_gemm_softmax_gemm(ops, B, Hs, P):
     """one-launch decode attention (transposed value cache) == logits GEMM + masked softmax + P V GEMM."""
