@@ -38,7 +38,9 @@ _PREFIX_SPLITS = [int(x) for x in os.environ.get("KAI0_PREFIX_SPLITS", "1,2,6").
 # split-K of the SigLIP tower's two narrow-output Linears at B = 1 (M = 3 x 256 rows; (M, N, K) -> split), swept on MI355X in round 5
 # (one gpurun call, p50 of the tower): out_proj 54 tiles x 18 K-tiles unsplit + a LayerNorm launch -> three chunks with the norm inside the
 # reduction launch; fc2 (K = 4304) five chunks on the two-stage configuration (270 blocks) -> four (216 blocks, <= one per CU: the
-# four-stage loop): tower 2.97 -> 2.77 ms
+# four-stage loop): tower 2.97 -> 2.77 ms.  Round 6 (eight-wave 128 x 128 tile, tower 2.54 ms): re-swept — (1 | 2, 4), (3, 2 | 3 | 6) all within
+# +0.01 ... +0.27 ms of (3, 4); prefix "1,1,6" / "1,2,8" / "1,2,4" +0.05 ... +0.1 ms against "1,2,6"; the persistent kernel for the 512-tile
+# pair GEMM +0.16 ms (one gpurun call, tools/infer_ab.sh)
 _B1_SPLITS = {(768, 1152, 1152): 3, (768, 1152, 4304): 4}
 
 
