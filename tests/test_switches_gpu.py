@@ -1,5 +1,5 @@
-"""Round 5: the switch list was pruned to the operational ones (13 environment variables: KAI0_SHARD_MODE / RS_ALGO / BUCKET_MB /
-FSDP_PREFETCH / TRIM_PROMPT / REMAT / INFER_GRAPH / EXPERT_STREAM / GEMM_PERSIST / ATTN_STORE_P / SPARSE_EMBED / INFER_CHECKSUM /
+"""The operational switches (14 environment variables, all read on the Python host: KAI0_SHARD_MODE / RS_ALGO / BUCKET_MB /
+FSDP_PREFETCH / TRIM_PROMPT / REMAT / INFER_GRAPH / EXPERT_STREAM / GEMM_PERSIST / GEMM_W8 / ATTN_STORE_P / SPARSE_EMBED / INFER_CHECKSUM /
 PREFIX_SPLITS, + the infrastructure ones: HIP_LIB, HIPCC_FLAGS, FORCE_COLLECTIVES, PALIGEMMA_TOKENIZER, BENCH_FSDP, GEMM_BREAKDOWN); the
 superseded variants behind the others were deleted, ablation hooks compile only under KAI0_HIPCC_FLAGS=-DKAI0_ABLATE.
 Every KAI0_* switch that selects another kernel, schedule or cache policy is a configuration of the shipped library
@@ -24,6 +24,7 @@ SWITCHES = [
     ({"KAI0_ATTN_STORE_P": "1", "KAI0_GEMM_PERSIST": "0"}, False),  # round 3's forms: stored-P attention (exact two-pass forward, backward
                                                                 # reads P), one GEMM block per tile
     ({"KAI0_GEMM_PERSIST": "2"}, True),                         # every eligible NT GEMM on the persistent kernel
+    ({"KAI0_GEMM_W8": "1"}, True),                              # the B = 1 passes' 128 x 128 GEMMs on four waves instead of eight (round 6)
     ({"KAI0_SPARSE_EMBED": "0"}, True),                         # embedding table through the dense AdamW pass (no idle-row skip)
     ({"KAI0_EXPERT_STREAM": "0"}, True),                        # action expert's chain on the main stream
     ({"KAI0_PREFIX_SPLITS": "1,1,6"}, False),                   # unsplit o_proj in the prefix pass (its norm then is a launch of its own)
