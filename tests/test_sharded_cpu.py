@@ -304,6 +304,27 @@ def _worker_trainer(rank, world, port, tmp, ckpt):
 
 
 @pytest.mark.timeout(300)
+def _worker_default_mode(rank, world, port, tmp):
+    _init(rank, world, port)
+    torch.set_num_threads(2)
+    os.environ.pop("KAI0_SHARD_MODE", None)
+    tr, model, obs, actions, noise, time = _tiny_oracle_trainer(world, rank, mode=None)
+    assert tr.engine.mode == "fsdp", tr.engine.mode  # north_star's partition (optimizer / gradients / parameters) whenever there are peers
+    loss = float(tr.train_step(_slice_obs(obs, rank), actions[rank : rank + 1], noise[rank : rank + 1], time[rank : rank + 1]))
+    assert loss == loss
+    tr.params_ready()
+    _done(rank, tmp)
+
+
+def test_trainer_default_partition_is_fsdp_with_peers_and_zero2_alone(monkeypatch):
+    """`Trainer` without a mode — fsdp (parameters sharded too) at world_size > 1, the collective-free zero2 engine on one
+    GPU; KAI0_SHARD_MODE / mode= still override."""
+    monkeypatch.delenv("KAI0_SHARD_MODE", raising=False)
+    tr, *_ = _tiny_oracle_trainer(1, 0, mode=None)
+    assert tr.engine.mode == "zero2"
+    _spawn(_worker_default_mode)
+
+
 def test_trainer_world2_matches_world1_and_checkpoint_resumes_at_another_world_size(tmp_path):
     ckpt = str(tmp_path)
     _spawn(_worker_trainer, 2, ckpt)
