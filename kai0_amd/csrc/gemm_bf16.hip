@@ -1475,9 +1475,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persistent_kernel(const GemmAr
         const bool col_ok = ccol < ((p.N + 7) & ~7);
         const bool fused_fast = p.act >= 2 && p.act <= 5 && p.bias == nullptr && p.gate == nullptr && p.residual == nullptr && !p.accumulate &&
                                 !p.out_f32 && p.nseg == 0 && (p.act == 4 || p.scale == 1.0f) && (p.act != 3 || p.pre_out != nullptr);
-        const bool simple_fast = p.simple_epi && p.act <= 1 && p.gate == nullptr && !p.out_f32 && p.scale == 1.0f && p.cmap.rpb == 0 &&
+        // (the same predicate as the tile kernel's; split_k == 1 is also what the host requires of a persistent launch)
+        const bool simple_fast = p.simple_epi && p.act <= 1 && p.split_k == 1 && p.gate == nullptr && !p.out_f32 && p.scale == 1.0f && p.cmap.rpb == 0 &&
                                  (N_ALIGNED8(p.N));
-        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab
+        auto to_slab = [&](int ti) {  // MFMA row-tile ti of the wave's sub-tile (16 rows x 64 columns) -> slab
             __builtin_amdgcn_wave_barrier();
             // (static indexing of acc: callers pass compile-time ti through the unrolled loops below)
 #pragma unroll
