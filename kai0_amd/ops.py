@@ -52,7 +52,7 @@ def _chk(t: torch.Tensor, dtype, name: str) -> None:
 # every call's descriptor — the library itself has no process-wide switch; tests and tools set them through `gemm_tuning(...)`.
 # (KAI0_GEMM_PERSIST=0 / 1 / 2 — never / the library's rule / every eligible NT launch — is read HERE, on the host side of the boundary.)
 GEMM_TUNING = {"tile_cfg": 0, "persist": {"0": 1, "2": 2}.get(os.environ.get("KAI0_GEMM_PERSIST", "1"), 0), "general_epilogue": 0,
-               "small_w8": int(os.environ.get("KAI0_GEMM_W8", "0"))}
+               "small_w8": {"0": 1, "2": 2}.get(os.environ.get("KAI0_GEMM_W8", "1"), 0)}  # env 0 / 1 / 2 = never / the rule / always, like KAI0_GEMM_PERSIST
 
 
 @contextlib.contextmanager

@@ -24,7 +24,7 @@ SWITCHES = [
     ({"KAI0_ATTN_STORE_P": "1", "KAI0_GEMM_PERSIST": "0"}, False),  # round 3's forms: stored-P attention (exact two-pass forward, backward
                                                                 # reads P), one GEMM block per tile
     ({"KAI0_GEMM_PERSIST": "2"}, True),                         # every eligible NT GEMM on the persistent kernel
-    ({"KAI0_GEMM_W8": "1"}, True),                              # the B = 1 passes' 128 x 128 GEMMs on four waves instead of eight (round 6)
+    ({"KAI0_GEMM_W8": "0"}, True),                              # the B = 1 passes' 128 x 128 GEMMs on four waves instead of eight (round 6)
     ({"KAI0_SPARSE_EMBED": "0"}, True),                         # embedding table through the dense AdamW pass (no idle-row skip)
     ({"KAI0_EXPERT_STREAM": "0"}, True),                        # action expert's chain on the main stream
     ({"KAI0_PREFIX_SPLITS": "1,1,6"}, False),                   # unsplit o_proj in the prefix pass (its norm then is a launch of its own)
