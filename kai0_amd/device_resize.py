@@ -56,14 +56,20 @@ def _pil_bilinear_taps(in_size: int, out_size: int):
     return idx, kk
 
 
+@functools.lru_cache(maxsize=64)
+def _taps_on(in_size: int, out_size: int, device: str):
+    """The tap tables on `device`, copied once per (size pair, device): per request they were 4 small pageable host-to-device copies
+    per frame, each a synchronisation (round 6)."""
+    idx_np, kk_np = _pil_bilinear_taps(in_size, out_size)
+    return torch.from_numpy(idx_np).to(device), torch.from_numpy(kk_np).to(device)
+
+
 def _resample_axis(img: torch.Tensor, out_size: int, axis: int) -> torch.Tensor:
     """One Pillow pass over `axis` of an int32 tensor [N, H, W, C] holding uint8 values."""
     in_size = img.shape[axis]
     if in_size == out_size:
         return img
-    idx_np, kk_np = _pil_bilinear_taps(in_size, out_size)
-    idx = torch.from_numpy(idx_np).to(img.device)
-    kk = torch.from_numpy(kk_np).to(img.device)
+    idx, kk = _taps_on(in_size, out_size, str(img.device))
     K = idx.shape[1]
     g = img.index_select(axis, idx.reshape(-1))  # [.., out * K, ..]
     shape = list(img.shape)

@@ -73,11 +73,16 @@ class Policy(BasePolicy):
         rs = self._device_resize
         if rs is not None and not all(isinstance(v, np.ndarray) and v.dtype == np.uint8 for v in inputs["image"].values()):
             inputs, rs = rs(inputs), None  # float frames: the host path, as before
-        inputs = _map_leaves(lambda x: torch.from_numpy(np.array(x)).to(dev)[None, ...], inputs)
+        inputs = self._to_device(inputs, dev)
         if rs is not None:
             from .device_resize import resize_with_pad_u8
 
-            inputs["image"] = {k: resize_with_pad_u8(v, rs.height, rs.width) for k, v in inputs["image"].items()}
+            frames = list(inputs["image"].values())
+            if len({(tuple(f.shape), f.dtype) for f in frames}) == 1:  # the cameras of one robot: one batched resize instead of one per frame
+                out = resize_with_pad_u8(torch.cat(frames, dim=0), rs.height, rs.width)
+                inputs["image"] = {k: out[i : i + 1] for i, k in enumerate(inputs["image"])}
+            else:
+                inputs["image"] = {k: resize_with_pad_u8(v, rs.height, rs.width) for k, v in inputs["image"].items()}
         kwargs = dict(self._sample_kwargs)
         if noise is not None:
             n = torch.from_numpy(noise).to(dev)
@@ -96,6 +101,32 @@ class Policy(BasePolicy):
         outputs = self._output_transform(outputs)
         outputs["policy_timing"] = {"infer_ms": model_time * 1000}
         return outputs
+
+    def _to_device(self, tree, dev):
+        """Batch axis + host-to-device move of every leaf.  On a GPU the leaves go through per-leaf PINNED staging buffers (kept across
+        requests: a Policy serves one request at a time and `infer` synchronises before it returns) and asynchronous copies — from
+        pageable numpy memory every leaf was a synchronous staged copy of its own (round 6: ~10 leaves, three of them 0.9 MB frames)."""
+        if torch.device(dev).type != "cuda":
+            return _map_leaves(lambda x: torch.from_numpy(np.array(x)).to(dev)[None, ...], tree)
+        stage = self.__dict__.setdefault("_pinned", {})
+
+        def put(path, x):
+            a = np.asarray(x)
+            if not a.flags.writeable or not a.flags.c_contiguous:
+                a = np.array(a)  # (torch.from_numpy wants a writable, contiguous array)
+            t = torch.from_numpy(a)
+            buf = stage.get(path)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = stage[path] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            buf.copy_(t)
+            return buf.to(dev, non_blocking=True)[None, ...]
+
+        def walk(node, path):
+            if isinstance(node, Mapping):
+                return {k: walk(v, path + (k,)) for k, v in node.items()}
+            return put(path, node)
+
+        return walk(tree, ())
 
     @property
     def metadata(self) -> dict[str, Any]:
