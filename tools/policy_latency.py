@@ -51,7 +51,8 @@ def run(trim: bool):
         wall.append((time.perf_counter() - t0) * 1e3)
         modelms.append(out["policy_timing"]["infer_ms"])
     wall.sort(), modelms.sort(), stages.sort()
-    return {"wall_p50_ms": wall[n_req // 2], "model_p50_ms": modelms[n_req // 2], "host_p50_ms": wall[n_req // 2] - modelms[n_req // 2],
+    return {"wall_p50_ms": wall[n_req // 2], "wall_p90_ms": wall[int(n_req * 0.9)], "wall_max_ms": wall[-1],  # (the tail: a p50 hides periodic stalls)
+            "model_p50_ms": modelms[n_req // 2], "host_p50_ms": wall[n_req // 2] - modelms[n_req // 2],
             "input_transform_p50_ms": stages[n_req // 2], "prompt_slots": int(model._engine.T)}  # fmt: skip
 
 
