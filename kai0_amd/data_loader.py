@@ -205,7 +205,7 @@ def _to_device_tree(tree, device, stream, pin: bool):
             return x
         if pin and x.device.type == "cpu" and not x.is_pinned():
             x = x.pin_memory()
-        return x.to(device, non_blocking=True)
+        return x.to(device, non_blocking=pin)
 
     if isinstance(tree, Observation):
         kw = {}
@@ -221,14 +221,19 @@ def _to_device_tree(tree, device, stream, pin: bool):
 
 class DeviceFeeder:
     """Iterate `(Observation, actions)` with every tensor already on `device`.  `depth` batches are prepared ahead by a
-    background thread: host collation / decode, pinning, and the H2D copies issued on a side stream; the consumer's stream
-    waits on the copy's event only (no host synchronisation, no copy on the training stream)."""
+    background thread: host collation / decode and the H2D copies issued on a side stream; the consumer's stream waits on the
+    copy's event only (no host synchronisation, no copy on the training stream).
+    The copies are plain blocking copies from pageable memory — the worker thread is the one that blocks.  Round 6 measured the
+    textbook form (`pin_memory()` + `non_blocking=True`) on this stack: every second or third batch a later device synchronisation
+    takes ~65 ms longer (12 ms steps: 11 77 12 11 77 ... against a flat 10 with pageable copies, `profiles/r06_pinned_h2d_stall.txt`;
+    the same stall showed in the serve path, `kai0_amd/policy.py::_to_device`).  `pin=True` keeps the old form for a re-test."""
 
     _END = object()
 
-    def __init__(self, loader, device, depth: int = 2):
+    def __init__(self, loader, device, depth: int = 2, pin: bool = False):
         self._loader, self._device, self._depth = loader, torch.device(device), max(1, depth)
         self._cuda = self._device.type == "cuda"
+        self._pin = bool(pin)
 
     def __iter__(self):
         q: queue.Queue = queue.Queue(maxsize=self._depth)
@@ -242,7 +247,7 @@ class DeviceFeeder:
                         return
                     if self._cuda:
                         with torch.cuda.stream(side):
-                            item = (_to_device_tree(obs, self._device, side, True), _to_device_tree(actions, self._device, side, True))
+                            item = (_to_device_tree(obs, self._device, side, self._pin), _to_device_tree(actions, self._device, side, self._pin))
                             ev = torch.cuda.Event()
                             ev.record(side)
                     else:

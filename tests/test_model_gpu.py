@@ -352,7 +352,7 @@ def test_advantage_estimator_against_reference_executed():
 
 
 def test_data_loader_device_feed_drives_the_trainer():
-    """FakeDataset -> transforms -> TorchDataLoader -> DeviceFeeder (pinned memory, side-stream H2D, event hand-off) ->
+    """FakeDataset -> transforms -> TorchDataLoader -> DeviceFeeder (worker thread, side-stream H2D, event hand-off) ->
     Trainer.train_step on the GPU: batches arrive on the device in loader order and the step consumes them."""
     from tiny import tiny_cfgs
 
