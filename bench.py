@@ -524,8 +524,6 @@ def main():
     # forward and backward, reduce-scatter from inside backward); zero2 (parameters resident: the natural mode with 288 GB per GPU) is
     # measured beside it (comm.zero2).  One GPU: nothing to shard, the engine's default.  KAI0_SHARD_MODE overrides.
     want_mode = os.environ.get("KAI0_SHARD_MODE") or ("fsdp" if world > 1 else "zero2")
-    trainer = Trainer(model, world_size=world, rank=rank, peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000,
-                      end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0, mode=want_mode)  # fmt: skip
     obs, actions = synthetic_batch(cfg, B, seed=1000 + rank, device=device)
 
     def barrier():
@@ -533,7 +531,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def make_trainer(mode):
+        return Trainer(model, world_size=world, rank=rank, peak_lr=2.5e-5, warmup_steps=1000, decay_steps=30000,
+                       end_lr=2.5e-6, weight_decay=1e-10, clip_norm=1.0, mode=mode)  # fmt: skip
+
+    # The first multi-GPU run of the fsdp partition happens on the driver's node, unattended: an error every rank raises alike while
+    # the engine is built or during the first warm-up step (nothing has been timed yet) falls back to zero2 on a fresh model instead
+    # of losing the line; the line says so (`headline_fallback`).  A hang is not an exception — nothing here can catch that.
+    headline_fallback = None
+    try:
+        trainer = make_trainer(want_mode)
+        if args.warmup > 0:
+            trainer.train_step(obs, actions)
+    except Exception as e:  # noqa: BLE001
+        if world == 1 or want_mode == "zero2":
+            raise
+        headline_fallback = f"{want_mode} failed before the timed region ({type(e).__name__}: {str(e)[:300]}); headline measured in zero2"
+        print(f"[bench] rank {rank}: {headline_fallback}", file=sys.stderr, flush=True)
+        model.set_unit_hooks(None)
+        del model
+        torch.cuda.empty_cache()
+        model = build_model(cfg, device, seed=0)
+        model.train()
+        trainer = make_trainer("zero2")
+        if args.warmup > 0:
+            trainer.train_step(obs, actions)
+    for _ in range(max(0, args.warmup - 1)):
         trainer.train_step(obs, actions)
     # Timed region: exactly `steps` training steps between barriers, nothing else on the stream.
     barrier()
@@ -776,6 +799,8 @@ def main():
                 json.dump(timer.breakdown(), open("gpurun_out/gemm_breakdown.json", "w"), indent=0)
         if comm is not None:
             out["comm"] = comm
+        if headline_fallback is not None:
+            out["headline_fallback"] = headline_fallback
         out["ranks"] = ranks
         if trimmed is not None:
             out["trimmed_prompt"] = trimmed
