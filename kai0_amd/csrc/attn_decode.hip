@@ -43,7 +43,7 @@ constexpr int DEC_HSPLIT = 4;   // P V kernel: head-dim ranges per query tile (6
 
 // Staging of a wave's operand rows through wave-private LDS.  The key / value caches are read by every query tile of a launch,
 // i.e. out of L2, and the direct MFMA-fragment pattern (16 rows x 64 B per wave-instruction) gets 31-34 GB/s per CU there
-// against 80-90 GB/s for contiguous 1-KiB runs (tools/probes/frag_load.hip).  Each wave therefore reads its rows as whole
+// against 80-90 GB/s for contiguous 1-KiB runs (round-2 probe frag_load.hip, profiles/HISTORY.md).  Each wave therefore reads its rows as whole
 // 512-B runs (two per instruction), parks them in its own LDS region (row stride 528 B) and takes its fragments from there
 // with ds_read_b128; no block barrier is involved.
 constexpr int DEC_ROWB = 512 + 16;            // LDS bytes per staged row (256 bf16 + 16 B: consecutive rows on distinct banks)
@@ -263,7 +263,7 @@ KAI0_API int kai0_attn_decode(const void* Q, const void* K, const void* Vt, void
     // few query tiles (B = 1: 25): eight key ranges / eight head-dim slices per tile instead of four, so that 200 blocks share
     // the staging of the caches instead of 100
     const int fine = 1;
-    // Range-major grids: a workgroup's XCD is its linear id % 8 (tools/probes/xcc_map.hip), so with the key range / head-dim slice in
+    // Range-major grids: a workgroup's XCD is its linear id % 8 (observed with a round-2 probe; MI355X_MICROARCH.md says the same: block b runs on XCD b % 8), so with the key range / head-dim slice in
     // blockIdx.x (8 or 4 of them) every block that stages the same rows of the K / V cache runs on the same XCD and the rows cross
     // the fabric once per launch instead of once per XCD (query-tile-major: 5.9 / 10.9 MB fetched per launch for 0.7 / 1.3 MB of
     // operands, profiles/r03_infer_chunk_pmc.txt).

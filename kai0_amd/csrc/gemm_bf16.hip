@@ -30,7 +30,7 @@ namespace {
 constexpr int BK = 64;
 
 // timing ablations (no DMA inside the K loop: the compute + LDS-read ceiling) exist only in builds made with
-// KAI0_HIPCC_FLAGS=-DKAI0_ABLATE (tools/gemm_ablate.py); the shipped kernels carry no ablation branch
+// KAI0_HIPCC_FLAGS=-DKAI0_ABLATE (with KAI0_GEMM_ABLATE=1 in the environment; the round-1 driver tools/gemm_ablate.py is in the git history); the shipped kernels carry no ablation branch
 #ifdef KAI0_ABLATE
 #define KAI0_ABL(p) ((p).ablate)
 #else
@@ -2069,7 +2069,7 @@ KAI0_API int kai0_gemm_bf16(const kai0_gemm_desc* d, kai0_stream_t stream) {
     const bool ps_ok = !forced && persist && big && d->a_kc && d->b_kc && batch == 1 && split == 1 &&
                        big_tiles >= (persist == 2 ? 512 : 2048) &&  // (B = 1 prefix MLP, 512 tiles = two per CU: 97 -> 136 us persistent)
                        (p.K % 8) == 0 && !d->rowvec && d->a_rpb == 0 && d->b_rpb == 0;
-    // the rule (measured inside the training step, tools/gpu_bd.sh): the wide MLP shapes gain — 30976 x 16384 x 2048 with the GeGLU
+    // the rule (measured inside the training step with KAI0_GEMM_BREAKDOWN=1, round 4): the wide MLP shapes gain — 30976 x 16384 x 2048 with the GeGLU
     // epilogues 993 -> 1046 TFLOP/s (1056 -> 1165 for the pair GEMM alone), x 2048 x 16384 1371 -> 1385 — while launches of < ~1000
     // tiles (q|k|v, o_proj, SigLIP) lose 1-8 %: their tiles are too few for the queue to pay for its hand-over
     const bool ps_rule = p.N >= 8192 || d->K >= 8192;

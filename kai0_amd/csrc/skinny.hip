@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, 1) void skinny_kernel(const SkinnyArgs p) 
 //   ALDS: the A rows of the block go through LDS — read from global as contiguous 1-KiB runs (64 lanes x 16 B along a row), written
 //   to LDS with 16 B of row padding, MFMA fragments read back with ds_read_b128.  Every block of a launch reads the same few
 //   hundred KB of activations out of L2, and the direct fragment pattern (16 rows x 64 B per wave-instruction) gets 31-34 GB/s
-//   per CU there against 80-90 GB/s for contiguous runs (tools/probes/frag_load.hip: 128 KB per CU 4.8 vs 2.8 us, 256 KB 8.2 vs
+//   per CU there against 80-90 GB/s for contiguous runs (round-2 probe frag_load.hip, git history / profiles/HISTORY.md: 128 KB per CU 4.8 vs 2.8 us, 256 KB 8.2 vs
 //   3.3 us): in the 1024-column projections the A operand, not the weight stream, was the longer load.
 // diagnostics (a workspace passed with split_k == -1 = phase trace, int64 [blocks][8]): wave 0 stamps the shader clock at the
 // phase boundaries of its block

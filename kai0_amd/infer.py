@@ -31,7 +31,7 @@ from .ops import BF16, F32, gemm, pick_split_k, round_up
 
 logger = logging.getLogger("kai0_amd")
 # split-K of the prefix pass's q|k|v, o_proj and down_proj GEMMs ("q,o,d"; 0 = ops.pick_split_k).  Swept on MI355X at B = 1
-# (tools/prefix_splits.sh): 1,1,6 -> prefix pass 6.52 ms; the automatic rule 6.80; everything else within 0.1-0.25 ms.  Round 3: with
+# (a round-2 sweep script, in the git history): 1,1,6 -> prefix pass 6.52 ms; the automatic rule 6.80; everything else within 0.1-0.25 ms.  Round 3: with
 # the post-attention RMSNorm inside o_proj's reduction launch (kai0hip.h norm_kind) a split o_proj costs no extra launch: 1,2,6 ->
 # 5.56 against 5.68 ms for 1,1,6 (3 and 4: 5.58 / 5.59)
 _PREFIX_SPLITS = [int(x) for x in os.environ.get("KAI0_PREFIX_SPLITS", "1,2,6").split(",")]

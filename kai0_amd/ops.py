@@ -348,7 +348,7 @@ def pick_split_k(M: int, N: int, K: int, batch: int = 1) -> int:
 
 
 # Split-K of the weight-gradient GEMMs (TN, contraction = B*S rows) whose output has few 256x256 tiles, measured on MI355X
-# with tools/tn_split_probe.py (us per launch at split 1/2/3/4/6/8): the best split fills ONE round of the 256 CUs
+# with a round-3 probe (tools/tn_split_probe.py in the git history; us per launch at split 1/2/3/4/6/8): the best split fills ONE round of the 256 CUs
 # (tiles x split <= 256), and fewer, longer chunks win when that leaves CUs idle anyway — a CU that shares the chip with
 # fewer running blocks stages its tiles faster.  Exact pi0.5 shapes at B = 32 first, then the rule they follow.
 _WGRAD_SPLIT = {(1152, 4304, 24576): 3, (4304, 1152, 24576): 3, (3456, 1152, 24576): 2, (1152, 1152, 24576): 6,
@@ -1039,7 +1039,7 @@ class GeluMlpFn(torch.autograd.Function):
     """SigLIP's MLP `fc2(gelu_tanh(fc1(x))) + residual` (modeling_siglip.py:348-362 + the residual add of :476-478) as one
     autograd node, so that the [M, F] intermediates (fc1 pre-activation, its GELU, and their gradients) can live in
     buffers whose rows are padded to a multiple of 128 bytes: F = 4304 gives 8608-byte rows, and GEMM tiles that start
-    mid-line cost the K = 4304 / N = 4304 GEMMs 15-18 % (tools/gemm_align_probe.py)."""
+    mid-line cost the K = 4304 / N = 4304 GEMMs 15-18 % (round-1 probe tools/gemm_align_probe.py, git history)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual):
